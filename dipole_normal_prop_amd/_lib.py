@@ -1,0 +1,89 @@
+"""ctypes binding of libdnp.so (include/dnp.h).  Plumbing only: device memory and streams are
+torch's, arithmetic is the library's.  There is no CPU fallback: if the library is missing or
+no HIP device is visible, the product path raises."""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdnp.so")
+
+_c_i64 = ctypes.c_int64
+_c_p = ctypes.c_void_p
+_c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/dnp.h declares
+SIGNATURES = {
+    "dnp_version": (ctypes.c_int, []),
+    "dnp_device_count": (ctypes.c_int, []),
+    "dnp_last_error": (ctypes.c_char_p, []),
+    "dnp_field_grad_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
+    "dnp_potential_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
+    "dnp_field_grad_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, ctypes.c_float,
+                                          _c_i64, _c_p, _c_i64, ctypes.c_int, ctypes.c_int, _c_p, _c_sz, _c_p]),
+    "dnp_field_grad_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, ctypes.c_double,
+                                          _c_i64, _c_p, _c_i64, ctypes.c_int, ctypes.c_int, _c_p, _c_sz, _c_p]),
+    "dnp_potential_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p,
+                                         _c_i64, _c_p, _c_sz, _c_p]),
+    "dnp_potential_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p,
+                                         _c_i64, _c_p, _c_sz, _c_p]),
+    "dnp_patch_fields_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64,
+                                            ctypes.c_float, _c_p, _c_p]),
+    "dnp_interactions_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p]),
+    "dnp_combine_fields_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, ctypes.c_int, _c_p]),
+    "dnp_point_greedy_workspace_bytes": (_c_sz, [_c_i64]),
+    "dnp_point_greedy_max_points": (ctypes.c_int, []),
+    "dnp_point_greedy_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_i64, ctypes.c_float, ctypes.c_int, _c_p, _c_p,
+                                            _c_p, _c_sz, _c_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class DnpError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libdnp.so and declare every prototype.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise DnpError(f"{LIB_PATH} not found - build it with `python -m dipole_normal_prop_amd.build` "
+                           "(there is no CPU fallback for the field kernels)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().dnp_last_error().decode("utf-8", "replace")
+        raise DnpError(f"libdnp error {rc}: {msg}")
+
+
+def require_device():
+    lib = load()
+    if not torch.cuda.is_available() or lib.dnp_device_count() < 1:
+        raise DnpError("no HIP device visible: the dipole field kernels run on MI355X (gfx950) only; "
+                       "there is no CPU fallback")
+    return lib
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def current_stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

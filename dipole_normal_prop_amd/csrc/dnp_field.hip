@@ -1,0 +1,238 @@
+// dnp_field.hip - K1 dnp_field_grad_* and K2 dnp_potential_* entry points.
+//
+// Host side: derive the reference's recursion leaves (field_utils.py:73-94: the source range is
+// halved at int(n/2) until <= max_pts), cut every leaf into enough chunks to fill 256 CUs, launch
+// pair_kernel over (target tiles x chunks) and then reduce_kernel, which sums the chunks of
+// each leaf in fp64, zeroes non-finite leaf components (field_utils.py:110-115 / :53-54) and
+// adds the leaves.
+#include <vector>
+
+#include "dnp_common.h"
+#include "pair_kernel.h"
+
+namespace dnp {
+
+constexpr int kKT = 2;                    // targets per lane
+constexpr int64_t kMinChunk = 512;        // do not cut leaves into pieces shorter than this
+constexpr int64_t kWantBlocks = 4096;     // ~16 workgroups per CU keeps the tail short
+constexpr size_t kSlabCap = (size_t)1 << 30;  // bytes of partial slab per round
+
+struct Plan {
+    // one entry per round; every round is a run of whole leaves
+    struct Round {
+        std::vector<int32_t> chunk_off;  // n_chunks+1 source offsets
+        std::vector<int32_t> leaf_first; // n_leaves+1 indices into chunk_off
+    };
+    std::vector<Round> rounds;
+    int64_t max_chunks = 0;  // largest n_chunks over the rounds
+};
+
+static void split_leaves(int64_t lo, int64_t hi, int64_t max_pts, std::vector<int64_t>& cuts) {
+    // field_utils.py:79-82: mid = int(S/2); halves are summed.  Leaves are emitted left to right.
+    if (max_pts > 0 && hi - lo > max_pts) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        split_leaves(lo, mid, max_pts, cuts);
+        split_leaves(mid, hi, max_pts, cuts);
+    } else {
+        cuts.push_back(hi);
+    }
+}
+
+static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem) {
+    Plan plan;
+    std::vector<int64_t> cuts;  // leaf end offsets
+    if (S > 0) split_leaves(0, S, max_pts, cuts);
+    const int64_t t_tiles = ceil_div(T > 0 ? T : 1, (int64_t)kBlock * kKT);
+    const int64_t n_leaves = (int64_t)cuts.size();
+    int64_t want = ceil_div(kWantBlocks, t_tiles);
+    if (want < n_leaves) want = n_leaves;
+    // chunk cap per round from the slab budget (at least one)
+    int64_t cap = (int64_t)(kSlabCap / ((size_t)(T > 0 ? T : 1) * nc * elem));
+    if (cap > kMaxChunks) cap = kMaxChunks;
+    if (cap < 1) cap = 1;
+
+    Plan::Round cur;
+    cur.chunk_off.push_back(0);
+    cur.leaf_first.push_back(0);
+    int64_t lo = 0;
+    for (int64_t l = 0; l < n_leaves; ++l) {
+        const int64_t hi = cuts[l];
+        const int64_t len = hi - lo;
+        int64_t m = (want * len + S - 1) / S;           // this leaf's share of the wanted chunks
+        const int64_t m_max = len / kMinChunk > 0 ? len / kMinChunk : 1;
+        if (m > m_max) m = m_max;
+        if (m > cap) m = cap;
+        if (m < 1) m = 1;
+        if ((int64_t)cur.chunk_off.size() - 1 + m > cap && cur.chunk_off.size() > 1) {
+            plan.rounds.push_back(cur);                 // start a new round with this leaf
+            cur = Plan::Round();
+            cur.chunk_off.push_back((int32_t)lo);
+            cur.leaf_first.push_back(0);
+        }
+        for (int64_t i = 1; i <= m; ++i) cur.chunk_off.push_back((int32_t)(lo + len * i / m));
+        cur.leaf_first.push_back((int32_t)cur.chunk_off.size() - 1);
+        lo = hi;
+    }
+    if (cur.chunk_off.size() > 1) plan.rounds.push_back(cur);
+    for (auto& r : plan.rounds)
+        if ((int64_t)r.chunk_off.size() - 1 > plan.max_chunks) plan.max_chunks = (int64_t)r.chunk_off.size() - 1;
+    return plan;
+}
+
+static size_t plan_workspace(const Plan& p, int64_t T, int nc, size_t elem) {
+    size_t b = (size_t)p.max_chunks * (size_t)(T > 0 ? T : 0) * nc * elem;
+    return (b + 255) & ~(size_t)255;
+}
+
+// ---- reduce: out[t][c] (+)= sum_leaves filter( sum_{chunks in leaf} partial[chunk][t][c] ) ----
+template <typename F>
+struct ReduceArgs {
+    const F* partial;       // [n_chunks][T][NC]
+    int64_t T;
+    const int64_t* tgt_idx; // for out_scatter
+    F* out;
+    int64_t ld_out;
+    int out_scatter;
+    int accumulate;
+    int n_leaves;
+    int32_t leaf_first[kMaxChunks + 1];
+};
+
+template <typename F, int NC>
+__global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs<F> a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // element (t, c)
+    if (i >= a.T * NC) return;
+    const int64_t t = i / NC;
+    const int c = (int)(i - t * NC);
+    const int64_t stride = a.T * NC;
+    double total = 0.0;
+    for (int l = 0; l < a.n_leaves; ++l) {
+        double s = 0.0;
+        for (int ch = a.leaf_first[l]; ch < a.leaf_first[l + 1]; ++ch) s += (double)a.partial[ch * stride + i];
+        const F f = (F)s;
+        // E_total[E_total.isinf()] = 0; E_total[E_total.isnan()] = 0   (per leaf, per component)
+        total += (__builtin_isfinite(f)) ? (double)f : 0.0;
+    }
+    const int64_t row = a.out_scatter ? a.tgt_idx[t] : t;
+    F* o = a.out + row * a.ld_out + c;
+    const F v = (F)total;
+    *o = a.accumulate ? (F)(*o + v) : v;
+}
+
+template <typename F, int MODE>
+static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
+                     const F* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
+                     F eps, int64_t max_pts, F* out, int64_t ld_out, int out_scatter, int accumulate,
+                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    constexpr int NC = (MODE == kField) ? 3 : 1;
+    clear_error();
+    DNP_REQUIRE(S >= 0 && T >= 0, "negative size S=%lld T=%lld", (long long)S, (long long)T);
+    DNP_REQUIRE(S <= INT32_MAX, "S=%lld exceeds the 2^31-1 source rows one call supports", (long long)S);
+    if (T == 0) return DNP_OK;
+    DNP_REQUIRE(tgt && out, "NULL tgt/out pointer");
+    DNP_REQUIRE(S == 0 || src, "NULL src pointer");
+    DNP_REQUIRE(ld_src >= 6 || S == 0, "ld_src=%lld < 6", (long long)ld_src);
+    DNP_REQUIRE(ld_tgt >= 3, "ld_tgt=%lld < 3", (long long)ld_tgt);
+    DNP_REQUIRE(ld_out >= (MODE == kField ? 3 : 1), "ld_out=%lld too small", (long long)ld_out);
+    DNP_REQUIRE(!out_scatter || tgt_idx, "out_scatter requires tgt_idx");
+
+    if (S == 0) {  // empty sum: zeros (the reference's sum over an empty dim)
+        if (!accumulate) {
+            ReduceArgs<F> ra{};
+            ra.partial = nullptr; ra.T = T; ra.tgt_idx = tgt_idx; ra.out = out; ra.ld_out = ld_out;
+            ra.out_scatter = out_scatter; ra.accumulate = 0; ra.n_leaves = 0;
+            const int64_t n = T * NC;
+            hipLaunchKernelGGL((reduce_kernel<F, NC>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, ra);
+            DNP_CHECK_HIP(hipGetLastError());
+        }
+        return DNP_OK;
+    }
+
+    const Plan plan = make_plan(S, T, max_pts, NC, sizeof(F));
+    const size_t need = plan_workspace(plan, T, NC, sizeof(F));
+    if (!workspace || workspace_bytes < need) {
+        set_error("workspace of %zu bytes required, %zu given", need, workspace ? workspace_bytes : (size_t)0);
+        return DNP_EWORKSPACE;
+    }
+    const int64_t t_tiles = ceil_div(T, (int64_t)kBlock * kKT);
+    DNP_REQUIRE(t_tiles <= INT32_MAX, "T too large");
+
+    bool first = true;
+    for (const auto& r : plan.rounds) {
+        const int n_chunks = (int)r.chunk_off.size() - 1;
+        PairArgs<F> pa{};
+        pa.src = src; pa.ld_src = ld_src; pa.src_idx = src_idx;
+        pa.tgt = tgt; pa.ld_tgt = ld_tgt; pa.tgt_idx = tgt_idx; pa.T = T;
+        pa.chunk_off_dev = nullptr; pa.chunk_base = 0; pa.tgt_group = nullptr;
+        pa.eps = eps; pa.partial = (F*)workspace;
+        for (int i = 0; i <= n_chunks; ++i) pa.chunk_off[i] = r.chunk_off[i];
+        const dim3 grid((unsigned)t_tiles, (unsigned)n_chunks);
+        if (MODE == kField && eps == F(0))
+            hipLaunchKernelGGL((pair_kernel<F, MODE, kKT, true>), grid, dim3(kBlock), 0, stream, pa);
+        else
+            hipLaunchKernelGGL((pair_kernel<F, MODE, kKT, false>), grid, dim3(kBlock), 0, stream, pa);
+        DNP_CHECK_HIP(hipGetLastError());
+
+        ReduceArgs<F> ra{};
+        ra.partial = (const F*)workspace; ra.T = T; ra.tgt_idx = tgt_idx; ra.out = out; ra.ld_out = ld_out;
+        ra.out_scatter = out_scatter; ra.accumulate = (accumulate || !first) ? 1 : 0;
+        ra.n_leaves = (int)r.leaf_first.size() - 1;
+        for (int i = 0; i <= ra.n_leaves; ++i) ra.leaf_first[i] = r.leaf_first[i];
+        const int64_t n = T * NC;
+        hipLaunchKernelGGL((reduce_kernel<F, NC>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, ra);
+        DNP_CHECK_HIP(hipGetLastError());
+        first = false;
+    }
+    return DNP_OK;
+}
+
+}  // namespace dnp
+
+using namespace dnp;
+
+extern "C" {
+
+size_t dnp_field_grad_workspace_bytes(int64_t S, int64_t T, int64_t max_pts) {
+    if (S <= 0 || T <= 0) return 256;
+    // sized for the widest element (f64) so one query serves both precisions
+    return plan_workspace(make_plan(S, T, max_pts, 3, sizeof(double)), T, 3, sizeof(double));
+}
+
+size_t dnp_potential_workspace_bytes(int64_t S, int64_t T, int64_t max_pts) {
+    if (S <= 0 || T <= 0) return 256;
+    return plan_workspace(make_plan(S, T, max_pts, 1, sizeof(double)), T, 1, sizeof(double));
+}
+
+int dnp_field_grad_f32(const float* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
+                       const float* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
+                       float eps, int64_t max_pts, float* out, int64_t ld_out, int out_scatter,
+                       int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    return run_pairs<float, kField>(src, S, ld_src, src_idx, tgt, T, ld_tgt, tgt_idx, eps, max_pts, out, ld_out,
+                                    out_scatter, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int dnp_field_grad_f64(const double* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
+                       const double* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
+                       double eps, int64_t max_pts, double* out, int64_t ld_out, int out_scatter,
+                       int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    return run_pairs<double, kField>(src, S, ld_src, src_idx, tgt, T, ld_tgt, tgt_idx, eps, max_pts, out, ld_out,
+                                     out_scatter, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int dnp_potential_f32(const float* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
+                      const float* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
+                      int64_t max_pts, float* out, int64_t ld_out,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    return run_pairs<float, kPotential>(src, S, ld_src, src_idx, tgt, T, ld_tgt, tgt_idx, 0.f, max_pts, out, ld_out,
+                                        0, 0, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int dnp_potential_f64(const double* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
+                      const double* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
+                      int64_t max_pts, double* out, int64_t ld_out,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    return run_pairs<double, kPotential>(src, S, ld_src, src_idx, tgt, T, ld_tgt, tgt_idx, 0.0, max_pts, out, ld_out,
+                                         0, 0, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

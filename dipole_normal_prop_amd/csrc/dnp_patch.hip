@@ -1,0 +1,121 @@
+// dnp_patch.hip - batched per-patch fields (the multi-GPU shard unit), the patch interaction
+// matrix (K3) and the ordered slab combination used by the greedy patch drivers
+// (field_utils.strongest_field_propagation{,_reps}, field_utils.py:207-348).
+#include "dnp_common.h"
+#include "pair_kernel.h"
+
+namespace dnp {
+
+constexpr int kPatchKT = 2;
+
+// W[k][j] = sum_{t in patch j} dE[k][t] . n_t    - one workgroup per (j, k), fp64 tree reduce.
+__global__ __launch_bounds__(256) void interactions_kernel(const float* __restrict__ dE, int64_t N,
+                                                           const float* __restrict__ pts, int64_t ld_pts,
+                                                           const int64_t* __restrict__ patch_off,
+                                                           const int64_t* __restrict__ patch_idx, int64_t P,
+                                                           double* __restrict__ W) {
+    const int64_t j = blockIdx.x, k = blockIdx.y;
+    const int64_t lo = patch_off[j], hi = patch_off[j + 1];
+    const float* slab = dE + k * N * 3;
+    double s = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int64_t t = patch_idx[i];
+        const float* e = slab + t * 3;
+        const float* n = pts + t * ld_pts + 3;
+        // per-point dot in fp32 like (E[patch] * pts[patch, 3:]).sum(dim=-1), patch sum in fp64
+        const float d = e[0] * n[0] + e[1] * n[1] + e[2] * n[2];
+        s += (double)d;
+    }
+    // wave reduce (64 lanes), then across the 4 waves through LDS
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ double part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) W[k * P + j] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// E[t][c] (+)= sum_i coef[i] * dE[slab[i]][t][c], sequentially in fp32 (visit order).
+__global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ dE, int64_t N3,
+                                                      const float* __restrict__ coef,
+                                                      const int64_t* __restrict__ slab, int64_t n,
+                                                      float* __restrict__ E, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N3) return;
+    float e = accumulate ? E[i] : 0.f;
+    for (int64_t q = 0; q < n; ++q) {
+        const float c = coef[q];
+        const float v = dE[slab[q] * N3 + i];
+        e = e + c * v;   // coef is +-1 (or 0): c*v is exact, so this is the reference's E + dE
+    }
+    E[i] = e;
+}
+
+}  // namespace dnp
+
+using namespace dnp;
+
+extern "C" {
+
+int dnp_patch_fields_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
+                         const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
+                         int64_t p_begin, int64_t p_end, float eps, float* dE, void* stream) {
+    clear_error();
+    DNP_REQUIRE(N >= 0 && P >= 0, "negative size");
+    DNP_REQUIRE(0 <= p_begin && p_begin <= p_end && p_end <= P, "bad patch range [%lld,%lld) of %lld",
+                (long long)p_begin, (long long)p_end, (long long)P);
+    if (N == 0 || p_begin == p_end) return DNP_OK;
+    DNP_REQUIRE(pts && patch_off && patch_idx && point_patch && dE, "NULL pointer");
+    DNP_REQUIRE(ld_pts >= 6, "ld_pts=%lld < 6", (long long)ld_pts);
+    const int64_t t_tiles = ceil_div(N, (int64_t)kBlock * kPatchKT);
+    const int64_t K = p_end - p_begin;
+    // grid.y is limited to 65535 workgroups: walk the patch range in slices
+    for (int64_t k0 = 0; k0 < K; k0 += 65535) {
+        const int64_t kn = (K - k0 < 65535) ? (K - k0) : 65535;
+        PairArgs<float> pa{};
+        pa.src = pts; pa.ld_src = ld_pts; pa.src_idx = patch_idx;
+        pa.tgt = pts; pa.ld_tgt = ld_pts; pa.tgt_idx = nullptr; pa.T = N;
+        pa.chunk_off_dev = patch_off; pa.chunk_base = p_begin + k0; pa.tgt_group = point_patch;
+        pa.eps = eps; pa.partial = dE + k0 * N * 3;
+        const dim3 grid((unsigned)t_tiles, (unsigned)kn);
+        if (eps == 0.f)
+            hipLaunchKernelGGL((pair_kernel<float, kField, kPatchKT, true>), grid, dim3(kBlock), 0,
+                               (hipStream_t)stream, pa);
+        else
+            hipLaunchKernelGGL((pair_kernel<float, kField, kPatchKT, false>), grid, dim3(kBlock), 0,
+                               (hipStream_t)stream, pa);
+        DNP_CHECK_HIP(hipGetLastError());
+    }
+    return DNP_OK;
+}
+
+int dnp_interactions_f32(const float* dE, int64_t K, int64_t N, const float* pts, int64_t ld_pts,
+                         const int64_t* patch_off, const int64_t* patch_idx, int64_t P, double* W,
+                         void* stream) {
+    clear_error();
+    DNP_REQUIRE(K >= 0 && N >= 0 && P >= 0, "negative size");
+    if (K == 0 || P == 0) return DNP_OK;
+    DNP_REQUIRE(dE && pts && patch_off && patch_idx && W, "NULL pointer");
+    DNP_REQUIRE(ld_pts >= 6, "ld_pts=%lld < 6", (long long)ld_pts);
+    DNP_REQUIRE(K <= 65535, "K=%lld slabs exceed one launch (65535)", (long long)K);
+    hipLaunchKernelGGL(interactions_kernel, dim3((unsigned)P, (unsigned)K), dim3(256), 0, (hipStream_t)stream, dE, N,
+                       pts, ld_pts, patch_off, patch_idx, P, W);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+int dnp_combine_fields_f32(const float* dE, int64_t K, int64_t N, const float* coef, const int64_t* slab,
+                           int64_t n, float* E, int accumulate, void* stream) {
+    clear_error();
+    DNP_REQUIRE(K >= 0 && N >= 0 && n >= 0, "negative size");
+    if (N == 0) return DNP_OK;
+    DNP_REQUIRE(E, "NULL E");
+    DNP_REQUIRE(n == 0 || (dE && coef && slab), "NULL pointer");
+    const int64_t N3 = N * 3;
+    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)ceil_div(N3, 256)), dim3(256), 0, (hipStream_t)stream, dE, N3,
+                       coef, slab, n, E, accumulate);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+}  // extern "C"

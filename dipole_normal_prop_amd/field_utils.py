@@ -1,0 +1,581 @@
+"""Drop-in counterpart of the reference's `field_utils` module for the dipole hot path.
+
+Same function names, argument order, defaults and in-place conventions as
+/root/reference/field_utils.py; the pair arithmetic runs in hand-written gfx950 kernels behind
+the C ABI of include/dnp.h (libdnp.so, bound through ctypes in _lib.py).  There is no CPU
+fallback: without the library or without a HIP device these functions raise.
+
+Device convention: tensors may live on the CPU or on a HIP device.  CPU tensors are staged to
+the current device for the call and the result comes back on the CPU, so `out.device ==
+in.device` as in the reference.  fp32 and fp64 are supported (the reference's socket path feeds
+fp64, util.py:71-77); other dtypes are computed in fp32 and cast back.
+
+Reference lines each function mirrors are cited in its docstring.
+"""
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import util
+
+__all__ = [
+    "measure_mean_potential", "potential", "field_grad", "field_edge_calculator",
+    "field_edge_calculator_bool", "field_edge_calculator_count", "self_interaction",
+    "self_interaction_all", "random_self_interaction", "reference_field",
+    "strongest_field_propagation_reps", "strongest_field_propagation",
+    "strongest_field_propagation_points", "torch", "np", "util",
+]
+
+# "auto": batched (all per-patch fields in one launch, greedy loop as P x P host arithmetic) when the
+# patches are disjoint, else the step-by-step form; "sequential" / "batched" force one.
+PATCH_MODE = "auto"
+# device bytes the batched drivers may spend on the [P, N, 3] slab before they fall back to two passes
+SLAB_BUDGET_BYTES = 48 << 30
+
+
+# ---------------------------------------------------------------------------------------------------
+# plumbing
+# ---------------------------------------------------------------------------------------------------
+def _compute_device() -> torch.device:
+    _lib.require_device()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stage(t: torch.Tensor, dev: torch.device, dtype: torch.dtype) -> torch.Tensor:
+    """Tensor on the compute device with unit inner stride (rows may be strided)."""
+    if t.device != dev or t.dtype != dtype:
+        t = t.to(device=dev, dtype=dtype)
+    if t.dim() != 2:
+        raise ValueError(f"expected a 2-d point tensor, got shape {tuple(t.shape)}")
+    if t.shape[0] > 1 and (t.stride(1) != 1 or t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    elif t.shape[0] <= 1 and t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def _work_dtype(*ts) -> torch.dtype:
+    return torch.float64 if any(t.dtype == torch.float64 for t in ts) else torch.float32
+
+
+def _idx(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    return t.to(device=dev, dtype=torch.int64).contiguous()
+
+
+def _pairs_into(kind: str, src, src_idx, tgt, tgt_idx, eps, max_pts, out, out_scatter=False, accumulate=False):
+    """Launch K1/K2 on staged device tensors.  src/tgt/out live on the compute device."""
+    lib = _lib.require_device()
+    S = src.shape[0] if src_idx is None else src_idx.shape[0]
+    T = tgt.shape[0] if tgt_idx is None else tgt_idx.shape[0]
+    f64 = src.dtype == torch.float64
+    if kind == "field":
+        nbytes = lib.dnp_field_grad_workspace_bytes(S, T, max_pts)
+    else:
+        nbytes = lib.dnp_potential_workspace_bytes(S, T, max_pts)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=src.device)
+    with torch.cuda.device(src.device):
+        stream = _lib.current_stream()
+        if kind == "field":
+            fn = lib.dnp_field_grad_f64 if f64 else lib.dnp_field_grad_f32
+            rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(src_idx), _lib.ptr(tgt), T, _ld(tgt), _lib.ptr(tgt_idx),
+                    float(eps), int(max_pts), _lib.ptr(out), out.stride(0) if out.shape[0] > 1 else 3,
+                    int(bool(out_scatter)), int(bool(accumulate)), _lib.ptr(ws), nbytes, stream)
+        else:
+            fn = lib.dnp_potential_f64 if f64 else lib.dnp_potential_f32
+            rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(src_idx), _lib.ptr(tgt), T, _ld(tgt), _lib.ptr(tgt_idx),
+                    int(max_pts), _lib.ptr(out), 1, _lib.ptr(ws), nbytes, stream)
+    _lib.check(rc)
+    return out
+
+
+def _field_like(kind, sources, means, eps, recursive, max_pts):
+    if sources.dim() != 2 or sources.shape[1] < 6:
+        raise ValueError(f"sources must be [S, 6], got {tuple(sources.shape)}")
+    if means.dim() != 2 or means.shape[1] < 3:
+        raise ValueError(f"means must be [T, >=3], got {tuple(means.shape)}")
+    in_dev, in_dtype = means.device, torch.result_type(sources, means)
+    dev = sources.device if sources.is_cuda else (means.device if means.is_cuda else _compute_device())
+    _lib.require_device()
+    wd = _work_dtype(sources, means)
+    src = _stage(sources.detach(), dev, wd)
+    tgt = _stage(means.detach(), dev, wd)
+    T = tgt.shape[0]
+    out = torch.empty((T, 3) if kind == "field" else (T,), dtype=wd, device=dev)
+    if T > 0:
+        _pairs_into(kind, src, None, tgt, None, eps, max_pts if recursive else 0, out)
+    if kind == "field":
+        # the reference prints (never raises) when a leaf produced Inf/NaN; the kernel has already
+        # zeroed them, so there is nothing left to warn about here.
+        pass
+    return out.to(device=in_dev, dtype=in_dtype) if (out.device != in_dev or out.dtype != in_dtype) else out
+
+
+# ---------------------------------------------------------------------------------------------------
+# field kernels
+# ---------------------------------------------------------------------------------------------------
+def measure_mean_potential(pc: torch.Tensor):
+    """Mean dipole potential over the 10^3 probe lattice (field_utils.py:7-9)."""
+    grid = util.gen_grid().to(pc.device)
+    return potential(pc, grid).mean()
+
+
+def potential(sources, means, eps=1e-5, recursive=True, max_pts=15000):
+    """Dipole potential phi[t] = sum_s (p_s . r)/|r|^3, r = x_s - x_t (field_utils.py:12-55).
+
+    `eps` is accepted and unused, as in the reference.  `recursive`/`max_pts` select the
+    reference's leaf structure (each leaf sum has Inf/NaN zeroed before the leaves are added)."""
+    return _field_like("potential", sources, means, eps, recursive, max_pts)
+
+
+def field_grad(sources, means, eps=1e-5, recursive=True, max_pts=15000):
+    """Dipole field E[t] = -sum_s (3 (p_s.r^) r^ - p_s)/(|r|^3 + eps) (field_utils.py:61-116).
+
+    Args:
+        sources: [S, 6] positions and dipole moments of the field sources
+        means:   [T, >=3] positions to evaluate at (only the first three columns are read)
+    Returns: [T, 3] field at the measurement positions (new tensor, inputs untouched)."""
+    return _field_like("field", sources, means, eps, recursive, max_pts)
+
+
+def field_edge_calculator(sources, means, if_save=False):
+    """Patch-to-patch interaction scalar used as a graph edge weight (field_utils.py:145-160):
+    w = 2 * sum_t E(S->T)[t].n_t / |S| * |T| (operator precedence as written there); returns
+    (w, -w) as numpy scalars."""
+    st_E = field_grad(sources, means)
+    st_interaction = (st_E * means[:, 3:]).sum(dim=-1).sum()
+    w = (st_interaction * 2) / sources.shape[0] * means.shape[0]
+    w = w.detach().cpu().numpy()
+    return w, w * -1
+
+
+def field_edge_calculator_bool(sources, means, if_save=False):
+    """Sign of the edge weight as (+1,-1) / (-1,+1) (field_utils.py:129-134)."""
+    w, _ = field_edge_calculator(sources, means, if_save)
+    return (1, -1) if w > 0 else (-1, 1)
+
+
+def field_edge_calculator_count(sources, means, if_save=False):
+    """field_utils.py:137-143: the weight is overwritten by |S|*|T|, so this is (+ST, -ST)."""
+    field_edge_calculator(sources, means, if_save)
+    w = sources.shape[0] * means.shape[0]
+    return (w, -w) if w > 0 else (-w, w)
+
+
+def self_interaction(nxyz, eps=1e-5):
+    """Interaction between two random halves of a cloud (field_utils.py:163-171)."""
+    assert nxyz.shape[1] == 6
+    num = nxyz.shape[0]
+    mask = torch.ones(num, dtype=torch.bool)
+    mask[torch.randperm(num)[:int(num / 2)]] = False
+    w, _ = field_edge_calculator(nxyz[mask], nxyz[~mask])
+    return w
+
+
+def self_interaction_all(nxyz, eps=1e-5):
+    """field_utils.py:174-177."""
+    assert nxyz.shape[1] == 6
+    w, _ = field_edge_calculator(nxyz, nxyz)
+    return w
+
+
+def random_self_interaction(nxyz, eps=1e-5):
+    """Self interaction after flipping a random half of the normals (field_utils.py:179-186)."""
+    assert nxyz.shape[1] == 6
+    flip = np.zeros(nxyz.shape[0], dtype=bool)
+    flip[np.random.permutation(nxyz.shape[0])[:int(nxyz.shape[0] / 2)]] = True
+    rand_n = nxyz.clone()
+    rand_n[torch.from_numpy(flip).to(nxyz.device), 3:] *= -1
+    w, _ = field_edge_calculator(rand_n, rand_n)
+    return w
+
+
+def reference_field(pc1, pc2):
+    """Transfer orientation from an oriented cloud pc1[S,6] to pc2 (field_utils.py:188-201):
+    3-column pc2 -> returns cat([xyz, E/|E|]) (rows with |E| == 0 keep E); 6-column pc2 -> normals
+    multiplied in place by sign(E.n) with `>= 0` counting as +1."""
+    with torch.no_grad():
+        E = field_grad(pc1, pc2, recursive=True)
+        if pc2.shape[1] == 3:
+            length = E.norm(dim=-1)
+            nz = length != 0
+            E[nz, :] = E[nz, :] / length[nz, None]
+            pc2 = torch.cat([pc2, E], dim=1)
+        else:
+            interactions = (E * pc2[:, 3:]).sum(dim=-1)
+            sign = (interactions >= 0).to(pc2.dtype) * 2 - 1
+            pc2[:, 3:] = pc2[:, 3:] * sign[:, None]
+        return pc2
+
+
+# ---------------------------------------------------------------------------------------------------
+# greedy patch drivers
+# ---------------------------------------------------------------------------------------------------
+def _flattest_patch(pts: torch.Tensor, patches: List[torch.Tensor]) -> int:
+    """argmin_k |lambda_min(cov(patch k))| (field_utils.py:303-306 / :230-233)."""
+    curv = [util.pca_eigen_values(pts[p]) for p in patches]
+    vals = np.abs(np.array([float(c[0][0]) for c in curv]))
+    return int(np.argmin(vals))
+
+
+def _csr(patches: List[torch.Tensor], dev) -> Tuple[torch.Tensor, torch.Tensor]:
+    sizes = [int(p.shape[0]) for p in patches]
+    off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64, device=dev)
+    idx = torch.cat([p.to(device=dev, dtype=torch.int64) for p in patches]) if patches else \
+        torch.zeros(0, dtype=torch.int64, device=dev)
+    return off, idx
+
+
+def _disjoint(idx: torch.Tensor, n: int) -> bool:
+    if idx.numel() == 0:
+        return True
+    return bool(torch.bincount(idx, minlength=n).max().item() <= 1)
+
+
+def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, eps: float) -> torch.Tensor:
+    lib = _lib.require_device()
+    N = work.shape[0]
+    dE = torch.empty((p1 - p0, N, 3), dtype=torch.float32, device=work.device)
+    with torch.cuda.device(work.device):
+        rc = lib.dnp_patch_fields_f32(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
+                                      off.shape[0] - 1, _lib.ptr(point_patch), p0, p1, float(eps), _lib.ptr(dE),
+                                      _lib.current_stream())
+    _lib.check(rc)
+    return dE
+
+
+def _interaction_rows(dE, work, off, idx) -> torch.Tensor:
+    lib = _lib.require_device()
+    K, N = dE.shape[0], dE.shape[1]
+    P = off.shape[0] - 1
+    W = torch.empty((K, P), dtype=torch.float64, device=work.device)
+    with torch.cuda.device(work.device):
+        rc = lib.dnp_interactions_f32(_lib.ptr(dE), K, N, _lib.ptr(work), work.stride(0), _lib.ptr(off),
+                                      _lib.ptr(idx), P, _lib.ptr(W), _lib.current_stream())
+    _lib.check(rc)
+    return W
+
+
+def _combine(dE, coef: torch.Tensor, slab: torch.Tensor, E: torch.Tensor, accumulate: bool):
+    lib = _lib.require_device()
+    K, N = dE.shape[0], dE.shape[1]
+    with torch.cuda.device(E.device):
+        rc = lib.dnp_combine_fields_f32(_lib.ptr(dE), K, N, _lib.ptr(coef), _lib.ptr(slab), coef.shape[0],
+                                        _lib.ptr(E), int(accumulate), _lib.current_stream())
+    _lib.check(rc)
+
+
+def greedy_order_from_interactions(W: np.ndarray, start: int):
+    """The greedy loop of field_utils.py:314-324 / :242-254 on the P x P interaction matrix:
+    I_j = sum_{k visited} sigma_k W[k, j]; pick argmax |I_j| over the remaining patches (first
+    maximum in patch order, as torch.argmax over the `remaining` list), flip when I_j < 0.
+    Returns (order[P], sigma[P], chosen_interaction[P-1])."""
+    P = W.shape[0]
+    sigma = np.ones(P)
+    visited = np.zeros(P, dtype=bool)
+    order = [start]
+    visited[start] = True
+    inter = W[start].astype(np.float64).copy()
+    chosen = []
+    for _ in range(P - 1):
+        mag = np.where(visited, -np.inf, np.abs(inter))
+        j = int(np.argmax(mag))
+        chosen.append(inter[j])
+        if inter[j] < 0:
+            sigma[j] = -1.0
+        visited[j] = True
+        order.append(j)
+        inter += sigma[j] * W[j]
+    return np.array(order), sigma, np.array(chosen)
+
+
+def _batched_patch_propagation(work: torch.Tensor, patches: List[torch.Tensor], start: int, diffuse: bool,
+                               eps: float = 1e-5, want_E: bool = True, shard=None):
+    """Core of the batched drivers on a device cloud `work[N,6]` (normals already weight-scaled).
+
+    Returns (order, sigma, chosen, E) where E[N,3] is the accumulated field of the diffuse form
+    (None unless want_E).  `shard` = (rank, world, gather_fn): patches are split over ranks, each
+    rank computes its slabs and W rows, gather_fn(all rows) returns the full W on every rank."""
+    dev = work.device
+    N, P = work.shape[0], len(patches)
+    off, idx = _csr(patches, dev)
+    point_patch = torch.full((N,), -1, dtype=torch.int64, device=dev)
+    sizes = (off[1:] - off[:-1])
+    point_patch[idx] = torch.repeat_interleave(torch.arange(P, device=dev), sizes)
+
+    rank, world, gather = (0, 1, None) if shard is None else shard
+    # contiguous blocks of patches per rank, balanced by pair count |patch| * N
+    bounds = _balanced_blocks(sizes.cpu().numpy(), world)
+    p_lo, p_hi = int(bounds[rank]), int(bounds[rank + 1])
+
+    per_slab = N * 3 * 4
+    batch = max(1, min(max(p_hi - p_lo, 1), SLAB_BUDGET_BYTES // max(per_slab, 1)))
+    keep = (p_hi - p_lo) <= batch
+    W_rows, kept = [], None
+    for b0 in range(p_lo, p_hi, batch):
+        b1 = min(b0 + batch, p_hi)
+        dE = _patch_slabs(work, off, idx, point_patch, b0, b1, eps)
+        W_rows.append(_interaction_rows(dE, work, off, idx))
+        if keep:
+            kept = dE
+        else:
+            del dE
+    W_local = torch.cat(W_rows, dim=0) if W_rows else torch.zeros((0, P), dtype=torch.float64, device=dev)
+    W_full = W_local if gather is None else gather(W_local, bounds)
+    order, sigma, chosen = greedy_order_from_interactions(W_full.cpu().numpy(), start)
+
+    E = None
+    if want_E and diffuse:
+        # E = sum over the visit order of sigma_k dE_k (field_utils.py:330-331), fp32
+        E = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+        mine = [k for k in order if p_lo <= k < p_hi]
+        coef = torch.tensor([sigma[k] for k in mine], dtype=torch.float32, device=dev)
+        if keep and kept is not None:
+            slab = torch.tensor([k - p_lo for k in mine], dtype=torch.int64, device=dev)
+            _combine(kept, coef, slab, E, False)
+        else:
+            for b0 in range(p_lo, p_hi, batch):
+                b1 = min(b0 + batch, p_hi)
+                dE = _patch_slabs(work, off, idx, point_patch, b0, b1, eps)
+                sel = [k for k in mine if b0 <= k < b1]
+                _combine(dE, torch.tensor([sigma[k] for k in sel], dtype=torch.float32, device=dev),
+                         torch.tensor([k - b0 for k in sel], dtype=torch.int64, device=dev), E, True)
+                del dE
+    return order, sigma, chosen, E, point_patch
+
+
+def _balanced_blocks(sizes: np.ndarray, world: int) -> np.ndarray:
+    """Cut 0..P into `world` contiguous blocks with near-equal total size; returns world+1 bounds."""
+    P = len(sizes)
+    if world <= 1:
+        return np.array([0, P])
+    csum = np.concatenate([[0], np.cumsum(sizes)])
+    targets = csum[-1] * np.arange(1, world) / world
+    cuts = np.searchsorted(csum, targets, side="left")
+    return np.concatenate([[0], np.clip(cuts, 0, P), [P]]).astype(np.int64)
+
+
+def _sequential_patch_propagation(work, patches: List[torch.Tensor], start: int, diffuse: bool, eps=1e-5):
+    """Step-by-step form: one field launch per greedy step, exactly the loop of
+    field_utils.py:308-335 with the masks expressed as index lists.  Works for overlapping
+    patches too.  Returns (order, sigma, chosen, E)."""
+    dev = work.device
+    N, P = work.shape[0], len(patches)
+    pidx = [p.to(device=dev, dtype=torch.int64) for p in patches]
+    E = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+    oriented = torch.zeros(N, dtype=torch.bool, device=dev)
+    all_rows = torch.arange(N, device=dev)
+
+    def add_field(k):
+        src_idx = pidx[k]
+        if diffuse:
+            m = torch.ones(N, dtype=torch.bool, device=dev)
+            m[src_idx] = False
+        else:
+            m = ~oriented
+        tgt_idx = all_rows[m]
+        if tgt_idx.numel():
+            _pairs_into("field", work, src_idx, work, tgt_idx, eps, 15000, E, out_scatter=True, accumulate=True)
+
+    remaining = list(range(P))
+    remaining.remove(start)
+    oriented[pidx[start]] = True
+    # E[~mask] = field_grad(pts[start], pts[~start])
+    tgt0 = all_rows[~oriented]
+    if tgt0.numel():
+        _pairs_into("field", work, pidx[start], work, tgt0, eps, 15000, E, out_scatter=True, accumulate=True)
+    order, sigma, chosen = [start], np.ones(P), []
+    while remaining:
+        dots = (E * work[:, 3:]).sum(dim=-1)
+        inter = torch.stack([dots[pidx[k]].sum() for k in remaining])
+        m = int(inter.abs().argmax().item())
+        k = remaining.pop(m)
+        v = float(inter[m])
+        chosen.append(v)
+        if v < 0:
+            work[pidx[k], 3:] *= -1
+            sigma[k] = -1.0
+        oriented[pidx[k]] = True
+        order.append(k)
+        add_field(k)
+    return np.array(order), sigma, np.array(chosen), E
+
+
+def _prepare_work(pts: torch.Tensor, weights):
+    """Device fp32 working copy of pts (normals scaled by clamp(weights, 0.1, 1))."""
+    dev = pts.device if pts.is_cuda else _compute_device()
+    work = pts.detach().to(device=dev, dtype=torch.float32).contiguous()
+    if work.data_ptr() == pts.data_ptr():
+        work = work.clone()
+    w = None
+    if weights is not None:
+        w = weights.detach().to(device=dev, dtype=torch.float32).clamp(0.1, 1)
+        work[:, 3:] = work[:, 3:] * w[:, None]
+    return work, w
+
+
+def strongest_field_propagation(pts, patches, all_patches, diffuse=False, weights=None, start_patch=None):
+    """Greedy patch orientation (field_utils.py:286-348).  `pts[N,6]` normals are updated in place.
+
+    patches:      list of (i, index tensor) - the filtered patches that receive the per-point
+                  diffuse sign pass
+    all_patches:  list of index tensors - every patch takes part in the greedy ordering
+    start_patch:  (extension, default None = as the reference) pin the starting patch instead of
+                  choosing the flattest one; the choice among near-planar patches is decided by
+                  fp32 noise in the reference and is not portable across BLAS builds."""
+    with torch.no_grad():
+        if len(all_patches) == 0:
+            return
+        work, w = _prepare_work(pts, weights)
+        dev = work.device
+        start = _flattest_patch(work, [p.to(dev) for p in all_patches]) if start_patch is None else int(start_patch)
+        _, idx = _csr(all_patches, dev)
+        mode = PATCH_MODE
+        if mode == "auto":
+            mode = "batched" if _disjoint(idx, work.shape[0]) else "sequential"
+        if mode == "batched":
+            order, sigma, chosen, E, point_patch = _batched_patch_propagation(work, list(all_patches), start, diffuse)
+            sig = torch.tensor(sigma, dtype=torch.float32, device=dev)
+            flip = torch.ones(work.shape[0], dtype=torch.float32, device=dev)
+            inpatch = point_patch >= 0
+            flip[inpatch] = sig[point_patch[inpatch]]
+            work[:, 3:] = work[:, 3:] * flip[:, None]
+        else:
+            order, sigma, chosen, E = _sequential_patch_propagation(work, list(all_patches), start, diffuse)
+        if diffuse:
+            for _, patch in patches:
+                p = patch.to(dev)
+                s = ((E[p] * work[p, 3:]).sum(dim=-1) > 0).float() * 2 - 1
+                work[p, 3:] = work[p, 3:] * s[:, None]
+        if w is not None:
+            work[:, 3:] = work[:, 3:] / w[:, None]
+        pts[:, 3:] = work[:, 3:].to(device=pts.device, dtype=pts.dtype)
+        strongest_field_propagation.last_trace = dict(order=order, sigma=sigma, chosen=chosen, start=start)
+
+
+def strongest_field_propagation_reps(input_pc, reps, diffuse=False, weights=None, start_patch=None):
+    """Greedy orientation on <=500 representatives per patch (field_utils.py:207-282): `reps` is a
+    list of (rep_idx, rest_idx); a flipped patch flips its rest points too; afterwards every
+    non-representative point takes the sign of the field of all representatives (:273-276)."""
+    input_pc = input_pc.detach()
+    with torch.no_grad():
+        if len(reps) == 0:
+            return
+        work, w = _prepare_work(input_pc, weights)
+        dev = work.device
+        rep_lists = [r.to(device=dev, dtype=torch.int64) for r, _ in reps]
+        rest_lists = [r.to(device=dev, dtype=torch.int64) for _, r in reps]
+        start = _flattest_patch(work, rep_lists) if start_patch is None else int(start_patch)
+        all_reps = torch.cat(rep_lists)
+        N = work.shape[0]
+        mode = PATCH_MODE
+        if mode == "auto":
+            mode = "batched" if _disjoint(all_reps, N) else "sequential"
+        if mode == "batched":
+            # compact sub-cloud of the representatives: targets of the loop are representatives only
+            sub = work[all_reps].contiguous()
+            sizes = [int(r.shape[0]) for r in rep_lists]
+            offs = np.concatenate([[0], np.cumsum(sizes)])
+            sub_patches = [torch.arange(int(offs[k]), int(offs[k + 1]), device=dev) for k in range(len(reps))]
+            order, sigma, chosen, E_sub, _ = _batched_patch_propagation(sub, sub_patches, start, diffuse)
+            E = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+            if E_sub is not None:
+                E[all_reps] = E_sub
+            for k in range(len(reps)):
+                if sigma[k] < 0:
+                    work[rep_lists[k], 3:] *= -1
+                    work[rest_lists[k], 3:] *= -1
+        else:
+            # the reps loop restricted to rep targets == patch loop on the rep sub-cloud; run it
+            # sequentially there and scatter back
+            sub = work[all_reps].contiguous()
+            sizes = [int(r.shape[0]) for r in rep_lists]
+            offs = np.concatenate([[0], np.cumsum(sizes)])
+            sub_patches = [torch.arange(int(offs[k]), int(offs[k + 1]), device=dev) for k in range(len(reps))]
+            order, sigma, chosen, E_sub = _sequential_patch_propagation(sub, sub_patches, start, diffuse)
+            E = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+            E[all_reps] = E_sub
+            for k in range(len(reps)):
+                if sigma[k] < 0:
+                    work[rep_lists[k], 3:] *= -1
+                    work[rest_lists[k], 3:] *= -1
+        if diffuse:
+            for r in rep_lists:
+                s = ((E[r] * work[r, 3:]).sum(dim=-1) > 0).float() * 2 - 1
+                work[r, 3:] = work[r, 3:] * s[:, None]
+        # every non-representative point: sign of the field of all representatives
+        is_rep = torch.zeros(N, dtype=torch.bool, device=dev)
+        is_rep[all_reps] = True
+        rest = torch.arange(N, device=dev)[~is_rep]
+        if rest.numel():
+            src_idx = torch.arange(N, device=dev)[is_rep]
+            E2 = torch.empty((rest.shape[0], 3), dtype=torch.float32, device=dev)
+            _pairs_into("field", work, src_idx, work, rest, 1e-5, 15000, E2)
+            s = ((E2 * work[rest, 3:]).sum(dim=-1) > 0).float() * 2 - 1
+            work[rest, 3:] = work[rest, 3:] * s[:, None]
+        if w is not None:
+            work[:, 3:] = work[:, 3:] / w[:, None]
+        input_pc[:, 3:] = work[:, 3:].to(device=input_pc.device, dtype=input_pc.dtype)
+        strongest_field_propagation_reps.last_trace = dict(order=order, sigma=sigma, chosen=chosen, start=start)
+
+
+def strongest_field_propagation_points(pts: torch.Tensor, diffuse=False, starting_point=0, verbose=False):
+    """Per-point greedy orientation (field_utils.py:353-388): N-1 sequential steps of
+    `E += field of the chosen point (eps=1e-6)`, `argmax |E.n|` over unvisited points, flip.
+    Runs as one persistent kernel (K4).  Normals are updated in place when pts already lives on
+    the device (the reference's own in-place contract, orient_simple.py:24 relies on it, holds
+    for CPU tensors here as well); returns pts."""
+    lib = _lib.require_device()
+    with torch.no_grad():
+        dev = pts.device if pts.is_cuda else _compute_device()
+        work = pts.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if work.data_ptr() == pts.data_ptr():
+            work = work.clone()
+        N = work.shape[0]
+        order = torch.empty(N, dtype=torch.int64, device=dev)
+        if N <= lib.dnp_point_greedy_max_points():
+            nbytes = lib.dnp_point_greedy_workspace_bytes(N)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.dnp_point_greedy_f32(_lib.ptr(work), N, work.stride(0), int(starting_point), 1e-6,
+                                              int(bool(diffuse)), _lib.ptr(order), None, _lib.ptr(ws), nbytes,
+                                              _lib.current_stream())
+            _lib.check(rc)
+        else:
+            order = _points_stepwise(work, diffuse, int(starting_point))
+        pts[:, 3:] = work[:, 3:].to(device=pts.device, dtype=pts.dtype)
+        strongest_field_propagation_points.last_trace = dict(order=order)
+        return pts
+
+
+def _points_stepwise(work, diffuse, start):
+    """Fallback for clouds beyond the persistent kernel's capacity: the loop of
+    field_utils.py:361-380 with one single-source field launch per step."""
+    dev = work.device
+    N = work.shape[0]
+    E = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+    visited = torch.zeros(N, dtype=torch.bool, device=dev)
+    order = torch.empty(N, dtype=torch.int64, device=dev)
+    cur = start
+    for step in range(N):
+        visited[cur] = True
+        order[step] = cur
+        _pairs_into("field", work[cur:cur + 1], None, work, None, 1e-6, 0, E, accumulate=True)
+        if step + 1 == N:
+            break
+        inter = (E * work[:, 3:]).sum(dim=-1)
+        mag = torch.where(visited, torch.full_like(inter, -1.0), inter.abs())
+        cur = int(mag.argmax().item())
+        if float(inter[cur]) < 0:
+            work[cur, 3:] *= -1
+    if diffuse:
+        s = ((E * work[:, 3:]).sum(dim=-1) > 0).float() * 2 - 1
+        work[:, 3:] = work[:, 3:] * s[:, None]
+    return order

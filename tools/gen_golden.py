@@ -1,0 +1,430 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the reference implementation (build container only).
+
+Imports /root/reference/field_utils.py *in place* (nothing is copied) with empty stub
+modules for the three optional dependencies that are absent offline (open3d, pymeshlab,
+gurobipy - none of them is touched by the field arithmetic), plus two API shims the
+reference needs on torch >= 2 / CPU-only hosts:
+    torch.symeig  -> torch.linalg.eigh      (util.py:498, inference_utils.py:57)
+    Tensor.cuda() -> identity               (field_utils.py:355 hard-codes .cuda())
+and writes small .npz fixtures under tests/golden/.  The fixtures (inputs + expected
+outputs) are data; they travel to the GPU box, the reference does not.
+
+Usage:  python tools/gen_golden.py [--only G1,G5,...]
+Fixture ids follow SURVEY.md section 8c (G1..G12) plus GH (host helpers).
+"""
+import argparse
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def import_reference():
+    for name in ("open3d", "pymeshlab", "gurobipy"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    torch.symeig = lambda a, eigenvectors=True: torch.linalg.eigh(a)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import field_utils  # noqa
+    import util  # noqa
+    import inference_utils_shim  # noqa  (see below)
+    return field_utils, util
+
+
+def load_cloud(util, name):
+    return util.xyz2tensor(open(f"{REF}/data/{name}.xyz").read())
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print(f"  wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def scramble_signs(pc, seed=0):
+    """Deterministic sign scrambling of the normals."""
+    g = torch.Generator().manual_seed(seed)
+    flip = torch.rand(pc.shape[0], generator=g) < 0.5
+    out = pc.clone()
+    out[flip, 3:] *= -1
+    return out, flip
+
+
+def ref_patches(util, pc, n_part, min_patch):
+    """The evidently intended divide_pc: grid partition followed by the merge
+    (util.divide_pc as committed omits the merge and returns list-wrapped tensors)."""
+    indices, ijk = util._divide_pc(pc[:, :3], n_part, min_patch=min_patch)
+    merged, _ = util.merge_nodes(pc, indices, ijk, min_patch)
+    return merged
+
+
+# ----------------------------------------------------------------------------------------
+def g1(fu, util):
+    g = torch.Generator().manual_seed(0)
+    src = torch.randn(64, 6, generator=g)
+    tgt = torch.randn(48, 6, generator=g)
+    out = dict(src=src, tgt=tgt)
+    for tag, eps in (("e5", 1e-5), ("e6", 1e-6)):
+        out[f"E6_{tag}"] = fu.field_grad(src, tgt, eps=eps)
+        out[f"E3_{tag}"] = fu.field_grad(src, tgt[:, :3].contiguous(), eps=eps)
+        out[f"E64_{tag}"] = fu.field_grad(src.double(), tgt.double(), eps=eps)
+        out[f"phi_{tag}"] = fu.potential(src, tgt, eps=eps)
+        out[f"phi64_{tag}"] = fu.potential(src.double(), tgt.double(), eps=eps)
+    # degenerate shapes
+    out["E_S1"] = fu.field_grad(src[:1], tgt)
+    out["E_T1"] = fu.field_grad(src, tgt[:1])
+    out["E_S0"] = fu.field_grad(src[:0], tgt)
+    save("G1_field_grad_small", **out)
+
+
+def g2(fu, util):
+    pc, _ = util.Transform.trans(load_cloud(util, "fandisk"))
+    s = pc[:300].clone()
+    t = torch.cat([pc[100:200], pc[1000:1100]], dim=0).clone()  # 100 coincident + 100 distinct
+    save("G2_zero_distance",
+         src=s, tgt=t,
+         E_self=fu.field_grad(s, s), E_self64=fu.field_grad(s.double(), s.double()),
+         E_part=fu.field_grad(s, t), E_part64=fu.field_grad(s.double(), t.double()))
+
+
+def g3(fu, util):
+    src = torch.tensor([[0.0, 0.0, 0.0, 0.0, 0.0, 1.0]])
+    tgt = torch.tensor([[0.0, 0.0, 0.5], [0.0, 0.0, -0.25], [0.7, 0.0, 0.0], [0.0, -0.3, 0.0],
+                        [0.3, 0.4, 0.0], [0.0, 0.0, 0.0], [0.1, 0.2, 0.3]])
+    out = dict(src=src, tgt=tgt)
+    for tag, eps in (("e5", 1e-5), ("e0", 0.0)):
+        out[f"E_{tag}"] = fu.field_grad(src, tgt, eps=eps)
+        out[f"phi_{tag}"] = fu.potential(src, tgt, eps=eps)
+    neg = src.clone()
+    neg[:, 3:] *= -1
+    out["E_neg"] = fu.field_grad(neg, tgt)
+    save("G3_analytic", **out)
+
+
+def g4(fu, util):
+    out = dict(grid=util.gen_grid())
+    for name in ("ok", "fandisk", "hand"):
+        pc, _ = util.Transform.trans(load_cloud(util, name))
+        phi = fu.potential(pc, util.gen_grid())
+        out[f"phi_{name}"] = phi
+        out[f"mean_{name}"] = fu.measure_mean_potential(pc)
+        out[f"phi64_{name}"] = fu.potential(pc.double(), util.gen_grid().double())
+    # a source exactly on a lattice node -> 0/0 = NaN in that column -> zeroed after the sum
+    pc, _ = util.Transform.trans(load_cloud(util, "ok"))
+    pc = pc[:500].clone()
+    pc[7, :3] = util.gen_grid()[345]
+    out["node_src"] = pc
+    out["node_phi"] = fu.potential(pc, util.gen_grid())
+    out["node_mean"] = fu.measure_mean_potential(pc)
+    save("G4_potential", **out)
+
+
+def g5(fu, util):
+    raw = load_cloud(util, "fandisk")
+    pc, _ = util.Transform.trans(raw)
+    g = torch.Generator().manual_seed(5)
+    rows = torch.randperm(pc.shape[0], generator=g)[:256].sort()[0]
+    t0 = time.time()
+    E = fu.field_grad(pc, pc)
+    print(f"  fandisk all-pairs reference: {time.time() - t0:.1f}s")
+    E64_rows = fu.field_grad(pc.double(), pc[rows].double())
+    nrm = E.norm(dim=-1)
+    save("G5_fandisk_allpairs",
+         raw=raw, pc=pc, rows=rows, E_rows=E[rows], E64_rows=E64_rows,
+         sum_norm=nrm.double().sum(), max_norm=nrm.max(), norm_all=nrm,
+         sign_all=((E * pc[:, 3:]).sum(-1) > 0))
+
+
+class _TorchProxy:
+    """Forwards to torch but records the python list handed to torch.tensor(...) so the
+    per-step interaction lists of the greedy drivers can be captured unmodified."""
+
+    def __init__(self, log):
+        self._log = log
+
+    def __getattr__(self, k):
+        return getattr(torch, k)
+
+    def tensor(self, data, *a, **k):
+        t = torch.tensor(data, *a, **k)
+        if isinstance(data, list):
+            self._log.append(t.clone())
+        return t
+
+
+def _run_patch_driver(fu, util, which, pc0, patches_arg, all_arg, diffuse, weights):
+    calls, inter = [], []
+    orig_fg, orig_torch = fu.field_grad, fu.torch
+
+    def rec_fg(sources, means, *a, **k):
+        calls.append((sources.shape[0], means.shape[0], sources[0, :3].clone(), sources[0, 3:].clone()))
+        return orig_fg(sources, means, *a, **k)
+
+    fu.field_grad = rec_fg
+    fu.torch = _TorchProxy(inter)
+    pts = pc0.clone()
+    try:
+        if which == "patch":
+            fu.strongest_field_propagation(pts, patches_arg, all_arg, diffuse=diffuse,
+                                           weights=None if weights is None else weights.clone())
+        else:
+            fu.strongest_field_propagation_reps(pts, patches_arg, diffuse=diffuse,
+                                                weights=None if weights is None else weights.clone())
+    finally:
+        fu.field_grad = orig_fg
+        fu.torch = orig_torch
+    return pts, calls, inter
+
+
+def _order_from_calls(calls, pc0, patch_first_pts):
+    """Map each recorded field_grad call to the patch whose first point is sources[0]."""
+    order, flipped = [], []
+    for (S, T, x0, n0) in calls:
+        hit = [k for k, (idx0, xyz) in enumerate(patch_first_pts) if torch.equal(xyz, x0)]
+        if len(hit) != 1:
+            order.append(-1)
+            flipped.append(False)
+            continue
+        k = hit[0]
+        order.append(k)
+        idx0 = patch_first_pts[k][0]
+        flipped.append(bool((n0 * pc0[idx0, 3:]).sum() < 0))
+    return np.array(order), np.array(flipped)
+
+
+def g6(fu, util):
+    pc, _ = util.Transform.trans(load_cloud(util, "fandisk"))
+    allp = ref_patches(util, pc, 30, 100)
+    print(f"  fandisk patches: {len(allp)}")
+    pc0, flip = scramble_signs(pc, 0)
+    # orient patches consistently inside themselves first (as orient_center does in the callers),
+    # then scramble whole patches so that the propagation has real work to do
+    g = torch.Generator().manual_seed(6)
+    pc_patch = pc.clone()
+    pflip = torch.rand(len(allp), generator=g) < 0.5
+    for k, idx in enumerate(allp):
+        if pflip[k]:
+            pc_patch[idx, 3:] *= -1
+    wts = torch.rand(pc.shape[0], generator=g)
+    patches = [(i, p) for i, p in enumerate(allp) if i % 5 != 3]   # a filtered subset for the diffuse pass
+    out = dict(pc_patchflip=pc_patch, pc_scrambled=pc0, weights=wts,
+               patch_off=np.cumsum([0] + [len(p) for p in allp]),
+               patch_idx=torch.cat(allp), filtered=np.array([i for i, _ in patches]),
+               curv=np.array([util.pca_eigen_values(pc[p])[0].item() for p in allp]))
+    firsts = None
+    for cname, cloud in (("pf", pc_patch), ("sc", pc0)):
+        for diffuse in (False, True):
+            for wname, w in (("nw", None), ("w", wts)):
+                tag = f"{cname}_{'d' if diffuse else 'n'}_{wname}"
+                t0 = time.time()
+                pts, calls, inter = _run_patch_driver(fu, util, "patch", cloud, patches, allp, diffuse, w)
+                base = cloud if w is None else torch.cat([cloud[:, :3], cloud[:, 3:] * w.clamp(0.1, 1)[:, None]], 1)
+                firsts = [(int(p[0]), base[int(p[0]), :3]) for p in allp]
+                order, flipped = _order_from_calls(calls, base, firsts)
+                chosen = [float(inter[i][inter[i].abs().argmax()]) for i in range(len(inter))]
+                out[f"order_{tag}"] = order
+                out[f"flipped_{tag}"] = flipped
+                out[f"chosen_{tag}"] = np.array(chosen)
+                out[f"sign_{tag}"] = ((pts[:, 3:] * cloud[:, 3:]).sum(-1) > 0)
+                out[f"normals_{tag}"] = pts[:, 3:]
+                print(f"  G6 {tag}: {time.time() - t0:.1f}s, start patch {order[0]}")
+    save("G6_patch_propagation", **out)
+
+
+def g7(fu, util):
+    pc, _ = util.Transform.trans(load_cloud(util, "fandisk"))
+    allp = ref_patches(util, pc, 30, 100)
+    g = torch.Generator().manual_seed(6)
+    pc_patch = pc.clone()
+    pflip = torch.rand(len(allp), generator=g) < 0.5
+    for k, idx in enumerate(allp):
+        if pflip[k]:
+            pc_patch[idx, 3:] *= -1
+    out = dict(pc_patchflip=pc_patch, patch_off=np.cumsum([0] + [len(p) for p in allp]),
+               patch_idx=torch.cat(allp))
+    for cap in (500, 50):
+        torch.manual_seed(1)
+        reps = []
+        for p in allp:
+            perm = torch.randperm(p.shape[0])
+            reps.append((p[perm[:cap]], p[perm[cap:]]))
+        out[f"rep_off_{cap}"] = np.cumsum([0] + [len(r) for r, _ in reps])
+        out[f"rep_idx_{cap}"] = torch.cat([r for r, _ in reps])
+        out[f"rest_off_{cap}"] = np.cumsum([0] + [len(r) for _, r in reps])
+        out[f"rest_idx_{cap}"] = torch.cat([r for _, r in reps])
+        for diffuse in (False, True):
+            tag = f"{cap}_{'d' if diffuse else 'n'}"
+            t0 = time.time()
+            pts, calls, inter = _run_patch_driver(fu, util, "reps", pc_patch, reps, None, diffuse, None)
+            firsts = [(int(r[0]), pc_patch[int(r[0]), :3]) for r, _ in reps]
+            order, flipped = _order_from_calls(calls[:len(allp)], pc_patch, firsts)
+            out[f"order_{tag}"] = order
+            out[f"flipped_{tag}"] = flipped
+            out[f"chosen_{tag}"] = np.array([float(t[t.abs().argmax()]) for t in inter])
+            out[f"sign_{tag}"] = ((pts[:, 3:] * pc_patch[:, 3:]).sum(-1) > 0)
+            print(f"  G7 {tag}: {time.time() - t0:.1f}s")
+    save("G7_reps_propagation", **out)
+
+
+def g8(fu, util):
+    raw = load_cloud(util, "ok")
+    pc, _ = util.Transform.trans(raw)
+    out = dict(raw=raw)
+    g = torch.Generator().manual_seed(8)
+    sub = torch.randperm(pc.shape[0], generator=g)[:1000].sort()[0]
+    for name, cloud in (("sub1000", pc[sub].clone()), ("full", pc)):
+        cloud0, _ = scramble_signs(cloud, 0)
+        for diffuse in (False, True):
+            order = []
+            orig_fg = fu.field_grad
+
+            def rec_fg(sources, means, *a, **k):
+                order.append(sources.storage_offset() // 6)
+                return orig_fg(sources, means, *a, **k)
+
+            fu.field_grad = rec_fg
+            t0 = time.time()
+            try:
+                pts = fu.strongest_field_propagation_points(cloud0.clone(), diffuse=diffuse, starting_point=0)
+            finally:
+                fu.field_grad = orig_fg
+            tag = f"{name}_{'d' if diffuse else 'n'}"
+            out[f"order_{tag}"] = np.array(order)
+            out[f"sign_{tag}"] = ((pts[:, 3:] * cloud0[:, 3:]).sum(-1) > 0)
+            print(f"  G8 {tag}: {time.time() - t0:.1f}s")
+        out[f"pc_{name}"] = cloud0
+    out["sub_rows"] = sub
+    save("G8_point_propagation", **out)
+
+
+def g9(fu, util):
+    src, _ = util.Transform.trans(load_cloud(util, "ok"))
+    g = torch.Generator().manual_seed(3)
+    tgt3 = (src[:, :3] + 1e-3 * torch.randn(src.shape[0], 3, generator=g)).contiguous()
+    tgt6, _ = scramble_signs(torch.cat([tgt3, src[:, 3:]], dim=1), 0)
+    out3 = fu.reference_field(src, tgt3.clone())
+    t6 = tgt6.clone()
+    out6 = fu.reference_field(src, t6)
+    save("G9_reference_field", src=src, tgt3=tgt3, tgt6=tgt6, out3=out3, out6=out6,
+         E64=fu.field_grad(src.double(), tgt3.double()))
+
+
+def g10(fu, util):
+    pc, _ = util.Transform.trans(load_cloud(util, "fandisk"))
+    allp = ref_patches(util, pc, 30, 100)
+    a, b = pc[allp[3]], pc[allp[4]]
+    w, invw = fu.field_edge_calculator(a, b)
+    wb = fu.field_edge_calculator_bool(a, b)
+    wc = fu.field_edge_calculator_count(a, b)
+    ws = fu.self_interaction_all(a)
+    save("G10_edge", a=a, b=b, w=w, invw=invw, wbool=np.array(wb), wcount=np.array(wc), wself=ws)
+
+
+def g11(fu, util):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(16000, 3, generator=g)
+    x = x / x.norm(dim=-1, keepdim=True) * 0.5
+    n = torch.randn(16000, 3, generator=g)
+    n = n / n.norm(dim=-1, keepdim=True)
+    pc = torch.cat([x, n], dim=1)
+    rows = torch.cat([torch.arange(64), torch.arange(8000 - 32, 8000 + 32), torch.arange(16000 - 64, 16000)])
+    t0 = time.time()
+    E = fu.field_grad(pc, pc)
+    print(f"  16000^2 reference with recursion: {time.time() - t0:.1f}s")
+    save("G11_recursion", seed=11, rows=rows, E_rows=E[rows],
+         E64_rows=fu.field_grad(pc.double(), pc[rows].double()),
+         pc_head=pc[:8], pc_tail=pc[-8:])
+
+
+def g12(fu, util):
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(100000, 3, generator=g)
+    n = x / x.norm(dim=-1, keepdim=True)
+    pc = torch.cat([n, n], dim=1)
+    pc, tr = util.Transform.trans(pc)
+    rows = torch.arange(0, 100000, 100000 // 64)[:64]
+    t0 = time.time()
+    E_rows = fu.field_grad(pc, pc[rows])
+    print(f"  100k sphere, 64 target rows: {time.time() - t0:.1f}s")
+    save("G12_sphere100k", head=pc[:16], center=tr.center, scale=tr.scale,
+         rows=rows, E_rows=E_rows, E64_rows=fu.field_grad(pc.double(), pc[rows].double()),
+         mean_potential=fu.measure_mean_potential(pc))
+
+
+def gh(fu, util):
+    """Host helpers on the path."""
+    raw = load_cloud(util, "fandisk")
+    pc, tr = util.Transform.trans(raw)
+    allp = ref_patches(util, pc, 30, 100)
+    ev = [util.pca_eigen_values(pc[p]) for p in allp]
+    oc = util.orient_center(pc[allp[0]].clone())
+    inv = tr.inverse(pc)
+    # fix_n_filter (inference_utils.py:52-71) on a copy, threshold 0.01 so that some patches are filtered
+    import inference_utils_shim as iu
+    pcf = pc.clone()
+    g = torch.Generator().manual_seed(2)
+    fl = torch.rand(pcf.shape[0], generator=g) < 0.5
+    pcf[fl, 3:] *= -1
+    pcf_in = pcf.clone()
+    kept = iu.fix_n_filter(pcf, [p.clone() for p in allp], 0.01)
+    # small grid partition without merge for a tiny cloud
+    small = pc[::37].clone()
+    ind_s, ijk_s = util._divide_pc(small[:, :3], 6)
+    save("GH_host_helpers", raw_head=raw[:32], center=tr.center, scale=tr.scale, pc_head=pc[:32],
+         inv_head=inv[:32], patch_off=np.cumsum([0] + [len(p) for p in allp]), patch_idx=torch.cat(allp),
+         eig_min=np.array([e[0].item() for e, _ in ev]), eig_vec=torch.stack([v for _, v in ev]),
+         oc_in=pc[allp[0]], oc_out=oc, filt_in=pcf_in, filt_out=pcf, filt_kept=np.array([i for i, _ in kept]),
+         small=small, small_off=np.cumsum([0] + [len(i[0]) for i in ind_s]),
+         small_idx=torch.cat([i[0] for i in ind_s]), small_ijk=torch.stack([j[0] for j in ijk_s]))
+    txt = "1 2 3\n4 5 6 0 0 1\nnan 1 2\n\n7.5 8 9e-1"
+    save("GH_xyz_parse", parsed=util.xyz2tensor(txt), parsed_noappend=util.xyz2tensor("1 2 3\n4 5 6", append_normals=False))
+
+
+def make_inference_shim():
+    """inference_utils.py imports models/ (torch_geometric, absent offline) at module level.
+    Only its pure-torch fix_n_filter is on the path; load that one function's source object by
+    executing the module with `models` stubbed - nothing is copied to disk."""
+    for name in ("models", "models.pointcnn"):
+        m = types.ModuleType(name)
+        m.PointCNN = object
+        sys.modules.setdefault(name, m)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("inference_utils_shim", f"{REF}/inference_utils.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["inference_utils_shim"] = mod
+    spec.loader.exec_module(mod)
+
+
+ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    torch.set_num_threads(os.cpu_count())
+    sys.path.insert(0, REF)
+    for name in ("open3d", "pymeshlab", "gurobipy"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    make_inference_shim()
+    fu, util = import_reference()
+    todo = [s for s in args.only.split(",") if s] or list(ALL)
+    for k in todo:
+        print(f"[{k}]")
+        t0 = time.time()
+        with torch.no_grad():
+            ALL[k](fu, util)
+        print(f"  {time.time() - t0:.1f}s")
