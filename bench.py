@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: dipole field-evaluations (source-target pairs) per second on the 100 000-point
+synthetic sphere of BASELINE.json (config 4: 256 patches), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A STEP is one pass of the data-parallel hot path over the cloud: every one of the 256 per-patch
+field evaluations `field_grad(pts[patch_k], pts[~patch_k])` (dnp_patch_fields_f32 - all of them in
+one launch per rank), the patch interaction matrix rows (dnp_interactions_f32) and, for N > 1, the
+RCCL all-gather of those rows that hands rank 0 everything the sequential greedy loop needs.
+Patches are sharded over the ranks in contiguous size-balanced blocks, so the total work is fixed
+as N grows ("strong").  Inputs are resident in HBM before the timed region.  `value` counts the
+algorithmic pairs sum_k |patch_k| * (N - |patch_k|) of all ranks per second of the slowest rank.
+
+Also printed on the same JSON line:
+  roofline      the pair kernel against the FP32 vector-ALU roofline that binds it (33 flop/pair,
+                DESIGN.md), timed live with HIP events around the launch; `hbm` carries the
+                algorithmic HBM GB/s the metric name asks for (<< 1 % of 8 TB/s by construction).
+  cpu_baseline  the oracle's dense-broadcast PyTorch port of the reference path, timed on this
+                box's host cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_POINTS = 100_000
+N_PATCHES = 256
+FLOP_PER_PAIR = 33            # 3 sub, 5 d2, rsq, d, fma, rcp, 5 p.r, 3 coefficient, 12 accumulate
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md (= the dense f32 MFMA peak)
+HBM_PEAK_GBS = 8000.0
+
+
+def sphere_cloud(n=N_POINTS, seed=1234):
+    """randn normalised, outward normals, unit-box Transform."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 3, generator=g)
+    nrm = x / x.norm(dim=-1, keepdim=True)
+    pc = torch.cat([nrm, nrm], dim=1)
+    pc[:, :3] -= pc[:, :3].mean(dim=0)[None, :]
+    pc[:, :3] = pc[:, :3] / (pc[:, :3].max(dim=0)[0] - pc[:, :3].min(dim=0)[0]).max()
+    return pc
+
+
+def fibonacci_patches(pc, P=N_PATCHES):
+    k = torch.arange(P, dtype=torch.float64) + 0.5
+    phi = torch.acos(1 - 2 * k / P)
+    theta = np.pi * (1 + 5 ** 0.5) * k
+    c = torch.stack([torch.cos(theta) * torch.sin(phi), torch.sin(theta) * torch.sin(phi), torch.cos(phi)], 1).float()
+    lab = (pc[:, 3:6] @ c.T).argmax(dim=1)
+    return [torch.nonzero(lab == j).flatten() for j in range(P)]
+
+
+def cpu_baseline(pc_cpu, seconds_target=15.0):
+    """Dense-broadcast PyTorch port of field_grad (oracle/dipole_oracle.py) on the host cores."""
+    from oracle import dipole_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = pc_cpu.shape[0]
+    t0 = time.perf_counter()
+    O.field_grad(pc_cpu, pc_cpu[:100])                        # calibrate
+    rate = n * 100 / (time.perf_counter() - t0)
+    n_t = int(min(max(rate * seconds_target / n, 100), 4000))
+    t0 = time.perf_counter()
+    O.field_grad(pc_cpu, pc_cpu[:n_t])
+    dt = time.perf_counter() - t0
+    return {"value": n * n_t / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"all {n} sources x first {n_t} targets of the same cloud ({n * n_t:.3g} pairs, {dt:.1f} s), "
+                      f"dense-broadcast PyTorch fp32 with the reference's 15000-row leaf recursion"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from dipole_normal_prop_amd import field_utils as fu
+    from dipole_normal_prop_amd import parallel
+
+    pc_cpu = sphere_cloud()
+    patches = fibonacci_patches(pc_cpu)
+    sizes = np.array([len(p) for p in patches])
+    pairs_total = float((sizes * (N_POINTS - sizes)).sum())
+    pts = pc_cpu.to(dev)
+    off, idx = fu._csr(patches, dev)
+    point_patch = torch.full((N_POINTS,), -1, dtype=torch.int64, device=dev)
+    point_patch[idx] = torch.repeat_interleave(torch.arange(N_PATCHES, device=dev), off[1:] - off[:-1])
+    bounds = fu._balanced_blocks(sizes, world)
+    p_lo, p_hi = int(bounds[rank]), int(bounds[rank + 1])
+    my_pairs = float((sizes[p_lo:p_hi] * (N_POINTS - sizes[p_lo:p_hi])).sum())
+
+    def step():
+        dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5)
+        W = fu._interaction_rows(dE, pts, off, idx)
+        return parallel.gather_rows(W, bounds)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        W = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        W = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = pairs_total * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: HIP events around the pair-kernel launch alone ------------------
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in ev:
+        a.record()
+        dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5)
+        b.record()
+    torch.cuda.synchronize()
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    # flops: the kernel also evaluates (and zeroes) the pairs inside each source patch
+    launch_pairs = float((sizes[p_lo:p_hi] * N_POINTS).sum())
+    tflops = launch_pairs * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
+    algo_bytes = 36.0 * N_POINTS + 12.0 * N_POINTS * (p_hi - p_lo)   # cloud read once + [K,N,3] slab written once
+    roofline = {"bound": "valu", "kernel": "pair_kernel<float,field,KT=2>", "achieved": tflops,
+                "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VALU_PEAK_TFLOPS,
+                "traffic": None, "launch_ms": k_ms, "flop_per_pair": FLOP_PER_PAIR,
+                "pairs_per_launch": launch_pairs,
+                "note": "FP32 vector ALU binds (no MFMA on this path); peak equals the dense f32 MFMA peak"}
+    hbm = {"bound": "hbm", "achieved": algo_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
+           "traffic": None}
+    prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            tr = json.load(open(prof))
+            roofline["traffic"] = hbm["traffic"] = tr.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    # sanity: the gathered matrix must be the full P x P on every rank and orient the sphere
+    assert W.shape == (N_PATCHES, N_PATCHES)
+    order, sigma, _ = fu.greedy_order_from_interactions(W.cpu().numpy(), 0)
+    signs_ok = bool(np.all(sigma == 1.0))        # unflipped outward sphere: nobody flips
+
+    out = None
+    if rank == 0:
+        out = {"metric": "dipole field-evals/sec (N x N pairs), 100k pts", "value": value, "unit": "pairs/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic",
+               "config": {"workload": "synthetic 100k-point sphere (seed 1234), 256 Fibonacci patches, all per-patch "
+                                      "fields + interaction matrix (BASELINE config 4)", "points": N_POINTS,
+                          "patches": N_PATCHES, "pairs_per_step": pairs_total,
+                          "parallelism": f"patch-sharded x{world}, RCCL all-gather of W rows"},
+               "roofline": roofline, "hbm": hbm, "signs_ok": signs_ok}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pc_cpu)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,7 +8,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdnp.so")
+LIB_PATH = os.environ.get("DNP_LIB", os.path.join(_HERE, "libdnp.so"))
 
 _c_i64 = ctypes.c_int64
 _c_p = ctypes.c_void_p

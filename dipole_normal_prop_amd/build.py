@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libdnp.so")
 SOURCES = ["dnp_api.hip", "dnp_field.hip", "dnp_patch.hip", "dnp_greedy.hip"]
 HEADERS = ["dnp_common.h", "pair_kernel.h", os.path.join("..", "..", "include", "dnp.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc", "-ffp-contract=off-dummy"]
+         "-fno-gpu-rdc", "-fno-slp-vectorize"]
 
 
 def _hipcc():

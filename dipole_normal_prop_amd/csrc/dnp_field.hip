@@ -12,7 +12,10 @@
 
 namespace dnp {
 
-constexpr int kKT = 2;                    // targets per lane
+#ifndef DNP_KT
+#define DNP_KT 2
+#endif
+constexpr int kKT = DNP_KT;               // targets per lane
 constexpr int64_t kMinChunk = 512;        // do not cut leaves into pieces shorter than this
 constexpr int64_t kWantBlocks = 4096;     // ~16 workgroups per CU keeps the tail short
 constexpr size_t kSlabCap = (size_t)1 << 30;  // bytes of partial slab per round

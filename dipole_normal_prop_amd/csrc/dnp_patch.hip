@@ -6,7 +6,10 @@
 
 namespace dnp {
 
-constexpr int kPatchKT = 2;
+#ifndef DNP_KT
+#define DNP_KT 2
+#endif
+constexpr int kPatchKT = DNP_KT;
 
 // W[k][j] = sum_{t in patch j} dE[k][t] . n_t    - one workgroup per (j, k), fp64 tree reduce.
 __global__ __launch_bounds__(256) void interactions_kernel(const float* __restrict__ dE, int64_t N,

@@ -1,0 +1,89 @@
+"""The C-ABI library builds, loads and exports every symbol include/dnp.h declares (CPU only:
+no compute is launched here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+from dipole_normal_prop_amd import _lib, build
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "dnp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dnp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    syms = header_symbols()
+    for name in ("dnp_field_grad_f32", "dnp_potential_f32", "dnp_patch_fields_f32", "dnp_interactions_f32",
+                 "dnp_point_greedy_f32", "dnp_last_error", "dnp_version", "dnp_device_count"):
+        assert name in syms
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in header_symbols():
+        assert hasattr(raw, name), f"{name} declared in include/dnp.h but not exported by libdnp.so"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes prototype in _lib.SIGNATURES"
+    for name in _lib.SIGNATURES:
+        assert name in header_symbols(), f"{name} bound in _lib.py but not declared in include/dnp.h"
+
+
+def test_version_and_error_string(lib):
+    assert lib.dnp_version() == 100
+    assert isinstance(lib.dnp_last_error(), bytes)
+    assert lib.dnp_device_count() >= 0
+
+
+def test_argument_validation_needs_no_device(lib):
+    # negative sizes / bad leading dimensions are rejected before any HIP call
+    rc = lib.dnp_field_grad_f32(None, -1, 6, None, None, 4, 3, None, 1e-5, 0, None, 3, 0, 0, None, 0, None)
+    assert rc == -1 and b"negative" in lib.dnp_last_error()
+    dummy = ctypes.c_void_p(16)
+    rc = lib.dnp_field_grad_f32(dummy, 4, 5, None, dummy, 4, 3, None, 1e-5, 0, dummy, 3, 0, 0, None, 0, None)
+    assert rc == -1 and b"ld_src" in lib.dnp_last_error()
+    rc = lib.dnp_field_grad_f32(dummy, 4, 6, None, dummy, 4, 3, None, 1e-5, 0, dummy, 3, 0, 0, None, 0, None)
+    assert rc == -3 and b"workspace" in lib.dnp_last_error()
+    rc = lib.dnp_point_greedy_f32(dummy, 10 ** 6, 6, 0, 1e-6, 0, None, None, None, 0, None)
+    assert rc == -1 and b"exceeds" in lib.dnp_last_error()
+    rc = lib.dnp_patch_fields_f32(dummy, 10, 6, dummy, dummy, 3, dummy, 2, 1, 1e-5, dummy, None)
+    assert rc == -1
+
+
+def test_workspace_queries(lib):
+    assert lib.dnp_field_grad_workspace_bytes(0, 10, 0) > 0
+    small = lib.dnp_field_grad_workspace_bytes(100, 100, 15000)
+    big = lib.dnp_field_grad_workspace_bytes(100000, 100000, 15000)
+    assert 0 < small < big < (2 << 30)
+    # 8 recursion leaves of 12 500 rows each at S = 100 000 (field_utils.py:73-94)
+    assert big >= 8 * 100000 * 3 * 8
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a device")
+def test_product_path_fails_loudly_without_a_device():
+    from dipole_normal_prop_amd import field_utils as fu
+    with pytest.raises(_lib.DnpError, match="no CPU fallback"):
+        fu.field_grad(torch.zeros(4, 6), torch.zeros(3, 3))
+    with pytest.raises(_lib.DnpError):
+        fu.potential(torch.zeros(4, 6), torch.zeros(3, 3))
+    with pytest.raises(_lib.DnpError):
+        fu.strongest_field_propagation_points(torch.zeros(4, 6))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "dipole_normal_prop_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+\.*oracle", src, flags=re.M), f"{fn} imports the oracle"
+            assert "c_oracle" not in src and "dipole_oracle" not in src, f"{fn} references an oracle module"

@@ -1,0 +1,105 @@
+"""The N>1 path on CPU: two gloo ranks shard the per-patch field evaluations, all-gather the rows
+of the interaction matrix and all-reduce the partial fields (dipole_normal_prop_amd/parallel.py).
+The device entry points are replaced by an oracle-backed stand-in (test infrastructure) so that
+the partition / gather / reduce plumbing is exercised without a GPU; the result must equal the
+reference's golden trace."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import csr_to_list, load_golden
+from dipole_normal_prop_amd import field_utils as fu
+from dipole_normal_prop_amd import parallel
+from oracle import dipole_oracle as O
+
+
+class OracleBackend:
+    """CPU stand-in for dnp_patch_fields_f32 / dnp_interactions_f32 / dnp_combine_fields_f32."""
+
+    @staticmethod
+    def slabs(work, off, idx, point_patch, b0, b1, eps):
+        N = work.shape[0]
+        dE = torch.zeros(b1 - b0, N, 3)
+        for k in range(b0, b1):
+            src = idx[off[k]:off[k + 1]]
+            others = point_patch != k
+            dE[k - b0][others] = O.field_grad(work[src], work[others], eps=eps)
+        return dE
+
+    @staticmethod
+    def interactions(dE, work, off, idx):
+        P = off.shape[0] - 1
+        dots = (dE.double() * work[None, :, 3:].double()).sum(-1)
+        return torch.stack([torch.stack([dots[k, idx[off[j]:off[j + 1]]].sum() for j in range(P)])
+                            for k in range(dE.shape[0])])
+
+    @staticmethod
+    def combine(dE, coef, slab, E, accumulate):
+        if not accumulate:
+            E.zero_()
+        for c, s in zip(coef.tolist(), slab.tolist()):
+            E += c * dE[s]
+
+
+def _case():
+    g = load_golden("G6_patch_propagation")
+    allp = csr_to_list(g["patch_off"], g["patch_idx"])[:10]
+    sub = torch.cat(allp)
+    remap = -torch.ones(g["pc_patchflip"].shape[0], dtype=torch.long)
+    remap[sub] = torch.arange(sub.shape[0])
+    cloud = torch.from_numpy(g["pc_patchflip"])[sub].clone()
+    patches = [remap[p] for p in allp]
+    return cloud, patches
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        cloud, patches = _case()
+        pts = cloud.clone()
+        parallel.sharded_patch_propagation(pts, list(enumerate(patches)), patches, diffuse=True, start_patch=3,
+                                           backend=OracleBackend)
+        tr = parallel.sharded_patch_propagation.last_trace
+        q.put((rank, pts[:, 3:].numpy().copy(), tr["order"].copy(), tr["sigma"].copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_reproduce_the_single_process_result():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    cloud, patches = _case()
+    ref_pts, ref_tr = O.strongest_field_propagation(cloud, list(enumerate(patches)), patches, diffuse=True,
+                                                    start_patch=3)
+    for rank, normals, order, sigma in res:
+        assert np.array_equal(order, ref_tr["order"])
+        assert np.array_equal((sigma < 0)[order], ref_tr["flipped"])
+        assert np.array_equal(normals, ref_pts[:, 3:].numpy())
+    assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_gather_rows_single_process_is_identity():
+    W = torch.arange(12, dtype=torch.float64).view(3, 4)
+    assert torch.equal(parallel.gather_rows(W, np.array([0, 3])), W)
+    assert parallel.world() == (0, 1)

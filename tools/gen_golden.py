@@ -190,11 +190,18 @@ def _run_patch_driver(fu, util, which, pc0, patches_arg, all_arg, diffuse, weigh
     return pts, calls, inter
 
 
-def _order_from_calls(calls, pc0, patch_first_pts):
+def _order_from_calls(calls, pc0, patch_first_pts, min_pts=None):
     """Map each recorded field_grad call to the patch whose first point is sources[0]."""
     order, flipped = [], []
     for (S, T, x0, n0) in calls:
+        # later calls pass pts[patch] (patch order); the first call passes pts[mask] (point order)
         hit = [k for k, (idx0, xyz) in enumerate(patch_first_pts) if torch.equal(xyz, x0)]
+        if len(hit) != 1 and min_pts is not None:
+            hit = [k for k, (idx0, xyz) in enumerate(min_pts) if torch.equal(xyz, x0)]
+            if len(hit) == 1:
+                order.append(hit[0])
+                flipped.append(False)
+                continue
         if len(hit) != 1:
             order.append(-1)
             flipped.append(False)
@@ -234,7 +241,8 @@ def g6(fu, util):
                 pts, calls, inter = _run_patch_driver(fu, util, "patch", cloud, patches, allp, diffuse, w)
                 base = cloud if w is None else torch.cat([cloud[:, :3], cloud[:, 3:] * w.clamp(0.1, 1)[:, None]], 1)
                 firsts = [(int(p[0]), base[int(p[0]), :3]) for p in allp]
-                order, flipped = _order_from_calls(calls, base, firsts)
+                mins = [(int(p.min()), base[int(p.min()), :3]) for p in allp]
+                order, flipped = _order_from_calls(calls, base, firsts, mins)
                 chosen = [float(inter[i][inter[i].abs().argmax()]) for i in range(len(inter))]
                 out[f"order_{tag}"] = order
                 out[f"flipped_{tag}"] = flipped
@@ -271,7 +279,8 @@ def g7(fu, util):
             t0 = time.time()
             pts, calls, inter = _run_patch_driver(fu, util, "reps", pc_patch, reps, None, diffuse, None)
             firsts = [(int(r[0]), pc_patch[int(r[0]), :3]) for r, _ in reps]
-            order, flipped = _order_from_calls(calls[:len(allp)], pc_patch, firsts)
+            mins = [(int(r.min()), pc_patch[int(r.min()), :3]) for r, _ in reps]
+            order, flipped = _order_from_calls(calls[:len(allp)], pc_patch, firsts, mins)
             out[f"order_{tag}"] = order
             out[f"flipped_{tag}"] = flipped
             out[f"chosen_{tag}"] = np.array([float(t[t.abs().argmax()]) for t in inter])
