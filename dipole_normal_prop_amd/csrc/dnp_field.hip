@@ -17,7 +17,10 @@ namespace dnp {
 #endif
 constexpr int kKT = DNP_KT;               // targets per lane
 constexpr int64_t kMinChunk = 512;        // do not cut leaves into pieces shorter than this
-constexpr int64_t kWantBlocks = 4096;     // ~16 workgroups per CU keeps the tail short
+#ifndef DNP_WANT_BLOCKS
+#define DNP_WANT_BLOCKS 8192
+#endif
+constexpr int64_t kWantBlocks = DNP_WANT_BLOCKS;  // ~32 workgroups per CU keeps the tail short (tuned: 2048..16384)
 constexpr size_t kSlabCap = (size_t)1 << 30;  // bytes of partial slab per round
 
 struct Plan {
@@ -90,7 +93,7 @@ static size_t plan_workspace(const Plan& p, int64_t T, int nc, size_t elem) {
 // ---- reduce: out[t][c] (+)= sum_leaves filter( sum_{chunks in leaf} partial[chunk][t][c] ) ----
 template <typename F>
 struct ReduceArgs {
-    const F* partial;       // [n_chunks][T][NC]
+    const double* partial;  // [n_chunks][T][NC] chunk sums, kept in fp64
     int64_t T;
     const int64_t* tgt_idx; // for out_scatter
     F* out;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs<F> a) {
     double total = 0.0;
     for (int l = 0; l < a.n_leaves; ++l) {
         double s = 0.0;
-        for (int ch = a.leaf_first[l]; ch < a.leaf_first[l + 1]; ++ch) s += (double)a.partial[ch * stride + i];
+        for (int ch = a.leaf_first[l]; ch < a.leaf_first[l + 1]; ++ch) s += a.partial[ch * stride + i];
         const F f = (F)s;
         // E_total[E_total.isinf()] = 0; E_total[E_total.isnan()] = 0   (per leaf, per component)
         total += (__builtin_isfinite(f)) ? (double)f : 0.0;
@@ -151,8 +154,8 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
         return DNP_OK;
     }
 
-    const Plan plan = make_plan(S, T, max_pts, NC, sizeof(F));
-    const size_t need = plan_workspace(plan, T, NC, sizeof(F));
+    const Plan plan = make_plan(S, T, max_pts, NC, sizeof(double));
+    const size_t need = plan_workspace(plan, T, NC, sizeof(double));
     if (!workspace || workspace_bytes < need) {
         set_error("workspace of %zu bytes required, %zu given", need, workspace ? workspace_bytes : (size_t)0);
         return DNP_EWORKSPACE;
@@ -163,21 +166,25 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
     bool first = true;
     for (const auto& r : plan.rounds) {
         const int n_chunks = (int)r.chunk_off.size() - 1;
-        PairArgs<F> pa{};
+        PairArgs<F, double> pa{};
         pa.src = src; pa.ld_src = ld_src; pa.src_idx = src_idx;
         pa.tgt = tgt; pa.ld_tgt = ld_tgt; pa.tgt_idx = tgt_idx; pa.T = T;
         pa.chunk_off_dev = nullptr; pa.chunk_base = 0; pa.tgt_group = nullptr;
-        pa.eps = eps; pa.partial = (F*)workspace;
+        pa.eps = eps; pa.partial = (double*)workspace;
         for (int i = 0; i <= n_chunks; ++i) pa.chunk_off[i] = r.chunk_off[i];
         const dim3 grid((unsigned)t_tiles, (unsigned)n_chunks);
-        if (MODE == kField && eps == F(0))
-            hipLaunchKernelGGL((pair_kernel<F, MODE, kKT, true>), grid, dim3(kBlock), 0, stream, pa);
+        // eps > 0 (what every caller of the reference passes): the short chain; otherwise the explicit one
+        const int variant = (MODE != kField) ? kFast : (eps > F(0) ? kFast : (eps == F(0) ? kNanCoinc : kRobust));
+        if (variant == kFast)
+            hipLaunchKernelGGL((pair_kernel<F, double, MODE, kKT, kFast>), grid, dim3(kBlock), 0, stream, pa);
+        else if (variant == kNanCoinc)
+            hipLaunchKernelGGL((pair_kernel<F, double, MODE, kKT, kNanCoinc>), grid, dim3(kBlock), 0, stream, pa);
         else
-            hipLaunchKernelGGL((pair_kernel<F, MODE, kKT, false>), grid, dim3(kBlock), 0, stream, pa);
+            hipLaunchKernelGGL((pair_kernel<F, double, MODE, kKT, kRobust>), grid, dim3(kBlock), 0, stream, pa);
         DNP_CHECK_HIP(hipGetLastError());
 
         ReduceArgs<F> ra{};
-        ra.partial = (const F*)workspace; ra.T = T; ra.tgt_idx = tgt_idx; ra.out = out; ra.ld_out = ld_out;
+        ra.partial = (const double*)workspace; ra.T = T; ra.tgt_idx = tgt_idx; ra.out = out; ra.ld_out = ld_out;
         ra.out_scatter = out_scatter; ra.accumulate = (accumulate || !first) ? 1 : 0;
         ra.n_leaves = (int)r.leaf_first.size() - 1;
         for (int i = 0; i <= ra.n_leaves; ++i) ra.leaf_first[i] = r.leaf_first[i];
@@ -197,7 +204,7 @@ extern "C" {
 
 size_t dnp_field_grad_workspace_bytes(int64_t S, int64_t T, int64_t max_pts) {
     if (S <= 0 || T <= 0) return 256;
-    // sized for the widest element (f64) so one query serves both precisions
+    // chunk sums are kept in fp64 for both precisions
     return plan_workspace(make_plan(S, T, max_pts, 3, sizeof(double)), T, 3, sizeof(double));
 }
 

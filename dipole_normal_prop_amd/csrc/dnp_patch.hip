@@ -75,18 +75,19 @@ int dnp_patch_fields_f32(const float* pts, int64_t N, int64_t ld_pts, const int6
     // grid.y is limited to 65535 workgroups: walk the patch range in slices
     for (int64_t k0 = 0; k0 < K; k0 += 65535) {
         const int64_t kn = (K - k0 < 65535) ? (K - k0) : 65535;
-        PairArgs<float> pa{};
+        PairArgs<float, float> pa{};
         pa.src = pts; pa.ld_src = ld_pts; pa.src_idx = patch_idx;
         pa.tgt = pts; pa.ld_tgt = ld_pts; pa.tgt_idx = nullptr; pa.T = N;
         pa.chunk_off_dev = patch_off; pa.chunk_base = p_begin + k0; pa.tgt_group = point_patch;
         pa.eps = eps; pa.partial = dE + k0 * N * 3;
         const dim3 grid((unsigned)t_tiles, (unsigned)kn);
-        if (eps == 0.f)
-            hipLaunchKernelGGL((pair_kernel<float, kField, kPatchKT, true>), grid, dim3(kBlock), 0,
-                               (hipStream_t)stream, pa);
+        const hipStream_t st = (hipStream_t)stream;
+        if (eps > 0.f)
+            hipLaunchKernelGGL((pair_kernel<float, float, kField, kPatchKT, kFast>), grid, dim3(kBlock), 0, st, pa);
+        else if (eps == 0.f)
+            hipLaunchKernelGGL((pair_kernel<float, float, kField, kPatchKT, kNanCoinc>), grid, dim3(kBlock), 0, st, pa);
         else
-            hipLaunchKernelGGL((pair_kernel<float, kField, kPatchKT, false>), grid, dim3(kBlock), 0,
-                               (hipStream_t)stream, pa);
+            hipLaunchKernelGGL((pair_kernel<float, float, kField, kPatchKT, kRobust>), grid, dim3(kBlock), 0, st, pa);
         DNP_CHECK_HIP(hipGetLastError());
     }
     return DNP_OK;

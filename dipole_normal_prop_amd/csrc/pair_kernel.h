@@ -11,16 +11,18 @@
 //   tiny kernel - deterministic (no float atomics), and the natural place for the reference's
 //   per-leaf Inf/NaN filter (field_utils.py:110-115).
 //
-// Arithmetic per pair (field mode), 33 flops in 24 full-rate + 2 half-rate VALU instructions:
-//   r = x_s - x_t; d2 = r.r; inv = rsq(d2); d = d2*inv; w = rcp(d2*d + eps)
-//   a = (p.r) * inv^2 * w;   A += a*r;  B += w*p;      E = -(3A - B)
-// which is field_utils.py:96-109 with r^ = r*inv folded in.  |r| == 0 is handled by
-// substituting d2 := 1e30 (one v_cmp + one v_cndmask): then d2*d overflows to +inf, w = 0,
-// a = 0 and the pair contributes exactly 0, as `E[zero_mask] = 0` does.
+// Arithmetic per pair (field mode): 19 full-rate + 2 quarter-rate (v_sqrt, v_rcp) VALU instructions
+//   r = x_s - x_t; d2 = r.r; w = 1/(|r|^3 + eps); a = (p.r) w / |r|^2;  A += a*r;  B += w*p;  E = -(3A - B)
+// which is field_utils.py:96-109 with r^ = r/|r| folded in (see pair_field for the exact chain and
+// for how |r| == 0 contributes exactly 0).  Measured on gfx950 (tools/ubench_valu.hip): v_fma_f32
+// issues at 2 cycles per wave64, v_pk_fma_f32 at 4 (no gain from packing), v_rsq/v_rcp/v_sqrt at
+// ~7.3, so the loop costs ~26.3 issue slots per pair and the FP32 vector ALU is the roofline.
 //
-// Accumulation: fp32 inside a run of FLUSH sources, fp64 across runs (one cvt+fma per FLUSH
-// sources, free) - the reference's own sum is a cascade sum (torch CPU), so a plain fp32 chain
-// over 10^5 terms would not stay within 1e-5 of it.
+// Accumulation: fp32 inside a run of kFlush sources, spread over kSets interleaved accumulator
+// sets (chains of 32 adds), fp64 across runs (one cvt+fma per run, ~1 % of the issue slots) - the
+// reference's own sum is a cascade sum (torch CPU); a plain fp32 chain over 10^5 terms would not
+// stay within 1e-5 of it, and with 128-long chains the accumulation error still dominated the
+// per-term rounding on cancellation-heavy rows (tools/gpu_accuracy.py).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,12 +30,13 @@
 namespace dnp {
 
 constexpr int kBlock = 256;       // threads per workgroup (4 waves, one per SIMD)
-constexpr int kFlush = 128;       // fp32 chain length before spilling into the fp64 sums
+constexpr int kFlush = 128;       // sources between two spills of the fp32 sums into the fp64 sums
+constexpr int kSets = 4;          // interleaved fp32 accumulator sets (chain length kFlush / kSets)
 constexpr int kMaxChunks = 128;   // by-value chunk table entries per launch
 
 enum PairMode { kField = 0, kPotential = 1 };
 
-template <typename F>
+template <typename F, typename PT = F>
 struct PairArgs {
     const F* src;            // [*, ld_src] rows (x,y,z,px,py,pz)
     int64_t ld_src;
@@ -46,7 +49,7 @@ struct PairArgs {
     int64_t chunk_base;            // first chunk handled by this launch (index into chunk_off_dev)
     const int64_t* tgt_group;      // per target-row group id; rows whose group == chunk id get 0
     F eps;
-    F* partial;              // [gridDim.y][T][NC]
+    PT* partial;             // [gridDim.y][T][NC]; PT = double keeps the chunk sums unrounded
     int32_t chunk_off[kMaxChunks + 1];  // by-value CSR offsets when chunk_off_dev == nullptr
 };
 
@@ -55,6 +58,8 @@ template <typename F> struct Math;
 template <> struct Math<float> {
     static __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
     static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static constexpr float kTiny = 1.17549435e-38f;   // FLT_MIN
     static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     static constexpr float kHuge = 1e30f;   // (1e30)^1.5 overflows fp32 -> w = rcp(inf) = 0
     static constexpr float kFar = 1e18f;    // padding source position: d2 = 3e36 (finite), d^3 = inf
@@ -62,25 +67,49 @@ template <> struct Math<float> {
 template <> struct Math<double> {
     static __device__ __forceinline__ double rsq(double x) { return 1.0 / __builtin_sqrt(x); }
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double sqrt(double x) { return __builtin_sqrt(x); }
+    static constexpr double kTiny = 2.2250738585072014e-308;   // DBL_MIN
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static constexpr double kHuge = 1e250;  // (1e250)^1.5 overflows fp64
     static constexpr double kFar = 1e150;   // d2 = 3e300 finite, d^3 = inf
 };
 
-template <typename F, bool NAN_COINC>
+// Variants of the per-pair chain (template parameter V of pair_field / pair_kernel):
+//   kFast    eps > 0 (every caller of the reference): 19 full-rate + 2 quarter-rate instructions
+//              d = sqrt(d2); den = d2*d + eps; g = d2*den + FLT_MIN; q = rcp(g); w = d2*q; a = (p.r)*q
+//            q = 1/(|r|^2 (|r|^3+eps)), so w = 1/(|r|^3+eps) and a = (p.r)/(|r|^2 (|r|^3+eps)).
+//            Adding FLT_MIN changes no g >= 2^-102 (it is below half an ulp) and makes g > 0 when
+//            |r| == 0: then q is finite, w = 0*q = 0 and a = 0*q = 0 - the pair contributes exactly 0,
+//            as `E[zero_mask] = 0` followed by /(0+eps) does (field_utils.py:106-108), without a
+//            compare/select.
+//   kRobust  any eps (also negative): explicit |r| == 0 test, rsq/rcp chain, 22 + 2 instructions.
+//   kNanCoinc  eps == 0: as kRobust, and a coincident pair yields NaN like the reference's 0/0
+//            (the leaf filter then zeroes the row, field_utils.py:112-115).
+enum PairVariant { kFast = 0, kRobust = 1, kNanCoinc = 2 };
+
+template <typename F, int V>
 __device__ __forceinline__ void pair_field(F sx, F sy, F sz, F px, F py, F pz, F tx, F ty, F tz, F eps,
                                            F& ax, F& ay, F& az, F& bx, F& by, F& bz) {
     using M = Math<F>;
     const F rx = sx - tx, ry = sy - ty, rz = sz - tz;
     const F d2 = M::fma(rz, rz, M::fma(ry, ry, rx * rx));
-    const bool coinc = (d2 == F(0));
-    const F d2m = coinc ? M::kHuge : d2;
-    const F inv = M::rsq(d2m);
-    const F d = d2m * inv;
-    F w = M::rcp(M::fma(d2m, d, eps));
-    if (NAN_COINC) w = coinc ? __builtin_nanf("") : w;   // eps == 0: the reference's 0/0
     const F pr = M::fma(pz, rz, M::fma(py, ry, px * rx));
-    const F a = pr * (inv * inv * w);
+    F w, a;
+    if (V == kFast) {
+        const F d = M::sqrt(d2);
+        const F den = M::fma(d2, d, eps);
+        const F q = M::rcp(M::fma(d2, den, M::kTiny));
+        w = d2 * q;
+        a = pr * q;
+    } else {
+        const bool coinc = (d2 == F(0));
+        const F d2m = coinc ? M::kHuge : d2;
+        const F inv = M::rsq(d2m);
+        const F d = d2m * inv;
+        w = M::rcp(M::fma(d2m, d, eps));
+        if (V == kNanCoinc) w = coinc ? F(__builtin_nanf("")) : w;
+        a = pr * (inv * inv * w);
+    }
     ax = M::fma(a, rx, ax);
     ay = M::fma(a, ry, ay);
     az = M::fma(a, rz, az);
@@ -102,8 +131,8 @@ __device__ __forceinline__ void pair_potential(F sx, F sy, F sz, F px, F py, F p
 // LDS image of one staged source row: two 16-byte slots, (x,y,z,px) and (py,pz,-,-).
 template <typename F> struct Vec4 { F x, y, z, w; };
 
-template <typename F, int MODE, int KT, bool NAN_COINC>
-__global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F> a) {
+template <typename F, typename PT, int MODE, int KT, int V>
+__global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
     using M = Math<F>;
     constexpr int NC = (MODE == kField) ? 3 : 1;
     __shared__ __attribute__((aligned(16))) Vec4<F> lds[2][kBlock][2];
@@ -174,40 +203,55 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F> a) {
         n_here = (n_here + 3) & ~3;                                // rows past s_end are padding rows
 
         for (int j0 = 0; j0 < n_here; j0 += kFlush) {
-            const int j1 = (j0 + kFlush < n_here) ? j0 + kFlush : n_here;
+            const int j1 = (j0 + kFlush < n_here) ? j0 + kFlush : n_here;   // multiples of kSets
             if (MODE == kField) {
-                F A[KT][3], B[KT][3];
+                // kSets interleaved accumulator sets: source j goes to set j % kSets, so an fp32 chain is
+                // kFlush / kSets = 32 adds long (no extra loop instructions, only registers)
+                F A[kSets][KT][3], B[kSets][KT][3];
 #pragma unroll
-                for (int k = 0; k < KT; ++k)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) A[k][c] = B[k][c] = F(0);
-#pragma unroll 4
-                for (int j = j0; j < j1; ++j) {
-                    const Vec4<F> s0 = lds[buf][j][0];
-                    const Vec4<F> s1 = lds[buf][j][1];
+                for (int u = 0; u < kSets; ++u)
 #pragma unroll
                     for (int k = 0; k < KT; ++k)
-                        pair_field<F, NAN_COINC>(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx[k], ty[k], tz[k], a.eps,
-                                                 A[k][0], A[k][1], A[k][2], B[k][0], B[k][1], B[k][2]);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) A[u][k][c] = B[u][k][c] = F(0);
+                for (int j = j0; j < j1; j += kSets) {
+#pragma unroll
+                    for (int u = 0; u < kSets; ++u) {
+                        const Vec4<F> s0 = lds[buf][j + u][0];
+                        const Vec4<F> s1 = lds[buf][j + u][1];
+#pragma unroll
+                        for (int k = 0; k < KT; ++k)
+                            pair_field<F, V>(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx[k], ty[k], tz[k], a.eps,
+                                                     A[u][k][0], A[u][k][1], A[u][k][2], B[u][k][0], B[u][k][1],
+                                                     B[u][k][2]);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < KT; ++k)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) acc[k][c] += 3.0 * (double)A[k][c] - (double)B[k][c];
+                    for (int c = 0; c < 3; ++c) {
+                        const F as = (A[0][k][c] + A[1][k][c]) + (A[2][k][c] + A[3][k][c]);
+                        const F bs = (B[0][k][c] + B[1][k][c]) + (B[2][k][c] + B[3][k][c]);
+                        acc[k][c] += 3.0 * (double)as - (double)bs;
+                    }
             } else {
-                F P[KT];
+                F P[kSets][KT];
 #pragma unroll
-                for (int k = 0; k < KT; ++k) P[k] = F(0);
-#pragma unroll 4
-                for (int j = j0; j < j1; ++j) {
-                    const Vec4<F> s0 = lds[buf][j][0];
-                    const Vec4<F> s1 = lds[buf][j][1];
+                for (int u = 0; u < kSets; ++u)
 #pragma unroll
-                    for (int k = 0; k < KT; ++k)
-                        pair_potential<F>(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx[k], ty[k], tz[k], P[k]);
+                    for (int k = 0; k < KT; ++k) P[u][k] = F(0);
+                for (int j = j0; j < j1; j += kSets) {
+#pragma unroll
+                    for (int u = 0; u < kSets; ++u) {
+                        const Vec4<F> s0 = lds[buf][j + u][0];
+                        const Vec4<F> s1 = lds[buf][j + u][1];
+#pragma unroll
+                        for (int k = 0; k < KT; ++k)
+                            pair_potential<F>(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx[k], ty[k], tz[k], P[u][k]);
+                    }
                 }
 #pragma unroll
-                for (int k = 0; k < KT; ++k) acc[k][0] += (double)P[k];
+                for (int k = 0; k < KT; ++k) acc[k][0] += (double)((P[0][k] + P[1][k]) + (P[2][k] + P[3][k]));
             }
         }
         if (it + 1 < n_tiles) store_row(buf ^ 1);
@@ -222,11 +266,11 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F> a) {
         if (t < a.T) {
             bool excluded = false;
             if (a.tgt_group) excluded = (a.tgt_group[trow[k]] == chunk_id);
-            F* o = a.partial + ((int64_t)chunk * a.T + t) * NC;
+            PT* o = a.partial + ((int64_t)chunk * a.T + t) * NC;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const double v = (MODE == kField) ? -acc[k][c] : acc[k][c];
-                o[c] = excluded ? F(0) : (F)v;
+                o[c] = excluded ? PT(0) : (PT)v;
             }
         }
     }

@@ -151,10 +151,15 @@ def test_G11_recursion_leaf_semantics(dev):
     pc = _g11_cloud().to(dev)
     E = fu.field_grad(pc, pc)                                        # 16 000 > max_pts: two source leaves
     assert rel_rowwise(E[t(g["rows"]).to(dev)].cpu(), g["E_rows"]) < TOL
-    E1 = fu.field_grad(pc, pc, recursive=False)
-    assert rel_rowwise(E1.cpu(), E.cpu()) < 1e-6
-    E2 = fu.field_grad(pc, pc, max_pts=1000)
-    assert rel_rowwise(E2.cpu(), E.cpu()) < 1e-6
+    # other leaf structures change only the summation tree: all agree with fp64 within tolerance
+    # (random normals: |E| is a random-walk residue, the hardest case for a relative bound)
+    E64 = fu.field_grad(pc.double(), pc.double()).cpu().numpy()
+    n64 = np.linalg.norm(E64, axis=1)
+    mag = term_magnitude(pc.cpu().numpy(), pc.cpu().numpy())
+    for other in (E, fu.field_grad(pc, pc, recursive=False), fu.field_grad(pc, pc, max_pts=1000)):
+        err = np.linalg.norm(other.cpu().numpy() - E64, axis=1)
+        assert np.all(err <= TOL * n64 + 16 * 2.0 ** -24 * mag)      # see test_ragged_sizes_against_oracle
+        assert np.quantile(err / n64, 0.99) < 3e-6 and np.median(err / n64) < 5e-7
 
 
 def test_recursion_leaf_nan_filter_is_per_leaf(dev):
@@ -180,6 +185,16 @@ def test_G12_sphere100k_rows_and_orientation_sign(dev):
 
 
 # ---- seeded inputs against the oracle: ragged sizes, gathers, accumulate ---------------------------------
+def term_magnitude(src, tgt, eps=1e-5):
+    """sum_s |term_s| per target: |3 (p.r^) r^ - p| / (|r|^3 + eps) <= 2 |p| / (|r|^3 + eps)."""
+    out = np.zeros(tgt.shape[0])
+    for i in range(0, tgt.shape[0], 256):
+        r = src[None, :, :3].astype(np.float64) - tgt[i:i + 256, None, :3].astype(np.float64)
+        d = np.linalg.norm(r, axis=-1)
+        out[i:i + 256] = (2 * np.linalg.norm(src[:, 3:6], axis=-1)[None, :] / (d ** 3 + eps) * (d > 0)).sum(axis=1)
+    return out
+
+
 @pytest.mark.parametrize("S,T", [(1, 1), (3, 700), (255, 257), (256, 512), (513, 1025), (2049, 33), (5000, 1)])
 def test_ragged_sizes_against_oracle(dev, S, T):
     gen = torch.Generator().manual_seed(S * 7919 + T)
@@ -187,7 +202,15 @@ def test_ragged_sizes_against_oracle(dev, S, T):
     tgt = torch.rand(T, 3, generator=gen) - 0.5
     tgt[: min(S, T) // 3] = src[: min(S, T) // 3, :3]               # some coincident pairs
     ref = c_oracle.field_grad_f64(src.numpy(), tgt.numpy())
-    assert rel_rowwise(fu.field_grad(src.to(dev), tgt.to(dev)).cpu(), ref) < TOL
+    E = fu.field_grad(src.to(dev), tgt.to(dev)).cpu().numpy()
+    # random dipoles: some rows are cancellation residues (|E| << sum of |terms|), where no fp32
+    # evaluation - the reference's included - can hold a bound relative to |E| alone; the bound that any
+    # fp32 evaluation can hold is relative to the magnitude of what is summed, so the row tolerance is
+    # 1e-5 |E| + 16 u * sum_s |term_s|  (u = 2^-24)
+    mag = term_magnitude(src.numpy(), tgt.numpy())[:, None]
+    err = np.linalg.norm(E - ref, axis=1)
+    assert np.all(err <= TOL * np.linalg.norm(ref, axis=1) + 16 * 2.0 ** -24 * mag[:, 0])
+    assert np.median(err / np.maximum(np.linalg.norm(ref, axis=1), 1e-30)) < 1e-6
     refp = c_oracle.potential_f64(src.numpy(), tgt.numpy())
     phi = fu.potential(src.to(dev), tgt.to(dev)).cpu().numpy()
     scale = np.abs(refp).max() if np.abs(refp).max() > 0 else 1.0
