@@ -238,6 +238,30 @@ def fix_n_filter(input_pc: torch.Tensor, patch_indices: List[torch.Tensor], thre
     return kept
 
 
+def estimate_normals(pc: torch.Tensor, max_nn: int = 30) -> torch.Tensor:
+    """Unoriented PCA normals from the max_nn nearest neighbours (the point itself included), returned
+    as [N,6] = (xyz, n).  The reference delegates this to open3d's KD-tree estimator
+    (util.py:551-567), which is not available offline; this is an own brute-force counterpart (chunked
+    distance matrix + top-k + batched 3x3 eigh, on whatever device pc lives on).  The sign of each
+    normal is arbitrary, as with open3d - fixing it is the job of the propagation."""
+    xyz = pc[:, :3].contiguous()
+    n = xyz.shape[0]
+    k = min(max_nn, n)
+    normals = torch.empty_like(xyz)
+    sq = (xyz * xyz).sum(dim=1)
+    step = max(1, min(n, (1 << 26) // max(n, 1)))
+    for i in range(0, n, step):
+        q = xyz[i:i + step]
+        d2 = sq[i:i + step, None] - 2.0 * (q @ xyz.T) + sq[None, :]
+        nn = d2.topk(k, dim=1, largest=False).indices            # [m, k]
+        nb = xyz[nn]                                             # [m, k, 3]
+        rel = nb - nb.mean(dim=1, keepdim=True)
+        cov = rel.transpose(1, 2) @ rel / k
+        _, v = torch.linalg.eigh(cov)
+        normals[i:i + step] = v[:, :, 0]
+    return torch.cat([xyz, normals], dim=1)
+
+
 def timer_factory():
     """A fresh timer class whose instances are `with` blocks printing their wall time; the class
     keeps a running total (print_total_time)."""

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 CSVs under gpurun_out/prof (tools/profile_r01.sh) into the committed summaries
+under profiles/:  <round>_kernel_stats.csv (the --stats table), <round>_pmc_summary.md and
+<round>_pmc_traffic.json (HBM bytes per launch of the dominant kernel, read back by bench.py).
+
+HBM bytes follow MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are KB, collected in separate
+--pmc passes; on gfx950 FETCH_SIZE under-reports wide (16 B/lane) streaming reads by exactly 2x and is
+uncalibrated for other widths - this kernel's global reads are 4-byte-per-lane staging loads, so both the
+raw figure and the 2x upper bound are recorded; WRITE_SIZE is taken as is."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "prof")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def counters(sub):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    path = os.path.join(src, sub, "r01_counter_collection.csv")
+    if not os.path.exists(path):
+        return d
+    for r in csv.DictReader(open(path)):
+        d[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return d
+
+
+shutil.copy(os.path.join(src, "trace", "r01_kernel_stats.csv"), os.path.join(dst, f"{rnd}_kernel_stats.csv"))
+stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "trace", "r01_kernel_stats.csv")))}
+allc = collections.defaultdict(dict)
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
+    for k, v in counters(sub).items():
+        for c, xs in v.items():
+            allc[k][c] = sum(xs) / len(xs)
+
+lines = [f"# {rnd}: rocprofv3 summary of `python bench.py --steps 10 --warmup 2 --no-cpu-baseline` (1x MI355X)", "",
+         "Per-dispatch averages. Kernel-trace stats and every PMC group come from separate runs "
+         "(tools/profile_r01.sh).", ""]
+traffic = {}
+for k in sorted(allc, key=lambda n: -float(stats.get(n, {"TotalDurationNs": 0})["TotalDurationNs"])):
+    if "dnp::" not in k:
+        continue
+    st = stats.get(k)
+    c = allc[k]
+    lines.append(f"## `{k[:110]}`")
+    if st:
+        lines.append(f"- calls {st['Calls']}, average {float(st['AverageNs']) / 1e3:.1f} us, min {float(st['MinNs']) / 1e3:.1f} us, "
+                     f"{st['Percentage']} % of GPU time")
+    if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
+        f, w = c.get("FETCH_SIZE", 0.0) * 1024, c.get("WRITE_SIZE", 0.0) * 1024
+        lines.append(f"- HBM: FETCH_SIZE {f / 1e6:.1f} MB raw ({2 * f / 1e6:.1f} MB with the gfx950 2x wide-read correction as "
+                     f"an upper bound), WRITE_SIZE {w / 1e6:.1f} MB -> {(f + w) / 1e6:.1f} .. {(2 * f + w) / 1e6:.1f} MB per launch")
+        if "pair_kernel" in k:
+            traffic = {"kernel": k, "fetch_bytes_raw": f, "write_bytes": w, "hbm_bytes_per_launch": f + w,
+                       "hbm_bytes_per_launch_upper": 2 * f + w,
+                       "avg_launch_us": float(st["AverageNs"]) / 1e3 if st else None}
+    if "SQ_INSTS_VALU" in c:
+        lines.append(f"- SQ: waves {c.get('SQ_WAVES', 0):.0f}, VALU wave-instructions {c['SQ_INSTS_VALU']:.4g}, "
+                     f"LDS instructions {c.get('SQ_INSTS_LDS', 0):.4g}, SALU {c.get('SQ_INSTS_SALU', 0):.4g}, "
+                     f"LDS bank-conflict cycles {c.get('SQ_LDS_BANK_CONFLICT', 0):.4g}")
+        lines.append(f"- SQ cycles (quad-cycle units): WAVE_CYCLES {c.get('SQ_WAVE_CYCLES', 0):.4g}, WAIT_INST_ANY "
+                     f"{c.get('SQ_WAIT_INST_ANY', 0):.4g}, WAIT_ANY {c.get('SQ_WAIT_ANY', 0):.4g}, ACTIVE_INST_ANY "
+                     f"{c.get('SQ_ACTIVE_INST_ANY', 0):.4g}, ACTIVE_INST_VALU {c.get('SQ_ACTIVE_INST_VALU', 0):.4g}")
+    if "GRBM_GUI_ACTIVE" in c and st:
+        clk = c["GRBM_GUI_ACTIVE"] / 8 / (float(st["AverageNs"]) * 1e-9) / 1e9
+        lines.append(f"- GRBM_GUI_ACTIVE {c['GRBM_GUI_ACTIVE']:.4g} (sum over 8 XCDs) -> effective clock {clk:.2f} GHz")
+    lines.append("")
+open(os.path.join(dst, f"{rnd}_pmc_summary.md"), "w").write("\n".join(lines))
+json.dump(traffic, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
+print("\n".join(lines))
