@@ -100,11 +100,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from dipole_normal_prop_amd import field_utils as fu
     from dipole_normal_prop_amd import parallel
@@ -113,10 +119,12 @@ def main():
     patches = fibonacci_patches(pc_cpu)
     sizes = np.array([len(p) for p in patches])
     pairs_total = float((sizes * (N_POINTS - sizes)).sum())
-    pts = pc_cpu.to(dev)
+    # layout: the cloud sorted by patch (what the drivers do, field_utils._batched_patch_propagation), so a
+    # patch is a contiguous row range and every slab / interaction access is coalesced
     off, idx = fu._csr(patches, dev)
-    point_patch = torch.full((N_POINTS,), -1, dtype=torch.int64, device=dev)
-    point_patch[idx] = torch.repeat_interleave(torch.arange(N_PATCHES, device=dev), off[1:] - off[:-1])
+    pts = pc_cpu.to(dev)[idx].contiguous()
+    point_patch = torch.repeat_interleave(torch.arange(N_PATCHES, device=dev), off[1:] - off[:-1])
+    idx = None
     bounds = fu._balanced_blocks(sizes, world)
     p_lo, p_hi = int(bounds[rank]), int(bounds[rank + 1])
     my_pairs = float((sizes[p_lo:p_hi] * (N_POINTS - sizes[p_lo:p_hi])).sum())
@@ -140,7 +148,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void interactions_kernel(const float* __restri
     const float* slab = dE + k * N * 3;
     double s = 0.0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const int64_t t = patch_idx[i];
+        const int64_t t = patch_idx ? patch_idx[i] : i;   // nullptr: patches are contiguous row ranges
         const float* e = slab + t * 3;
         const float* n = pts + t * ld_pts + 3;
         // per-point dot in fp32 like (E[patch] * pts[patch, 3:]).sum(dim=-1), patch sum in fp64
@@ -68,7 +68,7 @@ int dnp_patch_fields_f32(const float* pts, int64_t N, int64_t ld_pts, const int6
     DNP_REQUIRE(0 <= p_begin && p_begin <= p_end && p_end <= P, "bad patch range [%lld,%lld) of %lld",
                 (long long)p_begin, (long long)p_end, (long long)P);
     if (N == 0 || p_begin == p_end) return DNP_OK;
-    DNP_REQUIRE(pts && patch_off && patch_idx && point_patch && dE, "NULL pointer");
+    DNP_REQUIRE(pts && patch_off && point_patch && dE, "NULL pointer");   // patch_idx may be NULL (contiguous)
     DNP_REQUIRE(ld_pts >= 6, "ld_pts=%lld < 6", (long long)ld_pts);
     const int64_t t_tiles = ceil_div(N, (int64_t)kBlock * kPatchKT);
     const int64_t K = p_end - p_begin;
@@ -99,7 +99,7 @@ int dnp_interactions_f32(const float* dE, int64_t K, int64_t N, const float* pts
     clear_error();
     DNP_REQUIRE(K >= 0 && N >= 0 && P >= 0, "negative size");
     if (K == 0 || P == 0) return DNP_OK;
-    DNP_REQUIRE(dE && pts && patch_off && patch_idx && W, "NULL pointer");
+    DNP_REQUIRE(dE && pts && patch_off && W, "NULL pointer");             // patch_idx may be NULL (contiguous)
     DNP_REQUIRE(ld_pts >= 6, "ld_pts=%lld < 6", (long long)ld_pts);
     DNP_REQUIRE(K <= 65535, "K=%lld slabs exceed one launch (65535)", (long long)K);
     hipLaunchKernelGGL(interactions_kernel, dim3((unsigned)P, (unsigned)K), dim3(256), 0, (hipStream_t)stream, dE, N,

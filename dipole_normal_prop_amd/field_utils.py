@@ -316,6 +316,14 @@ def _batched_patch_propagation(work: torch.Tensor, patches: List[torch.Tensor], 
     point_patch = torch.full((N,), -1, dtype=torch.int64, device=dev)
     sizes = (off[1:] - off[:-1])
     point_patch[idx] = torch.repeat_interleave(torch.arange(P, device=dev), sizes)
+    # data layout for the kernels: the cloud sorted by patch (points in no patch last), so that a patch
+    # is a contiguous row range - sources stream linearly and K3 reads its slab rows coalesced
+    orig_work, orig_point_patch = work, point_patch
+    loose = torch.nonzero(point_patch < 0).flatten()
+    perm = torch.cat([idx, loose])
+    work = orig_work[perm].contiguous()
+    point_patch = orig_point_patch[perm].contiguous()
+    idx = None
 
     rank, world, gather = (0, 1, None) if shard is None else shard
     # contiguous blocks of patches per rank, balanced by pair count |patch| * N
@@ -355,7 +363,10 @@ def _batched_patch_propagation(work: torch.Tensor, patches: List[torch.Tensor], 
                 backend.combine(dE, torch.tensor([sigma[k] for k in sel], dtype=torch.float32, device=dev),
                          torch.tensor([k - b0 for k in sel], dtype=torch.int64, device=dev), E, True)
                 del dE
-    return order, sigma, chosen, E, point_patch
+    if E is not None:
+        E_sorted, E = E, torch.empty_like(E)
+        E[perm] = E_sorted
+    return order, sigma, chosen, E, orig_point_patch
 
 
 def _balanced_blocks(sizes: np.ndarray, world: int) -> np.ndarray:

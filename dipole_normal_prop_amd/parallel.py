@@ -26,6 +26,12 @@ def world():
     return 0, 1
 
 
+def _host_staged(t: torch.Tensor) -> bool:
+    """gloo moves host memory only: device tensors are staged through the CPU (rehearsals of the N>1
+    path on a single-GPU box); with nccl (RCCL) the collective runs on the device buffers over xGMI."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def gather_rows(W_local: torch.Tensor, bounds: np.ndarray, group=None) -> torch.Tensor:
     """All-gather the per-rank row blocks of W ([rows_r, P] fp64, rows_r = bounds[r+1]-bounds[r])
     into the full [P, P] matrix on every rank.  Blocks are padded to the largest block so that a
@@ -38,8 +44,13 @@ def gather_rows(W_local: torch.Tensor, bounds: np.ndarray, group=None) -> torch.
     pad = int(rows.max())
     buf = torch.zeros((pad, P), dtype=W_local.dtype, device=W_local.device)
     buf[: W_local.shape[0]] = W_local
-    out = torch.empty((size, pad, P), dtype=W_local.dtype, device=W_local.device)
-    dist.all_gather_into_tensor(out.view(size * pad, P), buf, group=group)
+    if _host_staged(buf):
+        parts = [torch.empty((pad, P), dtype=W_local.dtype) for _ in range(size)]
+        dist.all_gather(parts, buf.cpu(), group=group)
+        out = torch.stack(parts).to(W_local.device)
+    else:
+        out = torch.empty((size, pad, P), dtype=W_local.dtype, device=W_local.device)
+        dist.all_gather_into_tensor(out.view(size * pad, P), buf, group=group)
     return torch.cat([out[r, : int(rows[r])] for r in range(size)], dim=0)
 
 
@@ -47,7 +58,12 @@ def reduce_field(E_partial: torch.Tensor, group=None) -> torch.Tensor:
     """Sum the per-rank partial fields (each rank combined its own slabs) on every rank."""
     _, size = world()
     if size > 1:
-        dist.all_reduce(E_partial, op=dist.ReduceOp.SUM, group=group)
+        if _host_staged(E_partial):
+            host = E_partial.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            E_partial.copy_(host)
+        else:
+            dist.all_reduce(E_partial, op=dist.ReduceOp.SUM, group=group)
     return E_partial
 
 

@@ -97,7 +97,9 @@ int dnp_potential_f64(const double* src, int64_t S, int64_t ld_src, const int64_
 /* ---- batched per-patch fields: the multi-GPU shard unit --------------------------------
  *
  * For patches k in [p_begin, p_end) of a partition of pts[N, >=6] given in CSR form
- * (patch_off[P+1], patch_idx[patch_off[P]], both device int64):
+ * (patch_off[P+1], patch_idx[patch_off[P]], both device int64; patch_idx == NULL means the cloud is
+ * already sorted by patch, i.e. patch k is the row range [patch_off[k], patch_off[k+1]) - the layout
+ * the drivers use, because it makes every slab / interaction access coalesced):
  *
  *   dE[k - p_begin][t] = field of patch k on point t, for every t NOT in patch k (rows of
  *   patch k itself are written as 0) - i.e. exactly the dE of one greedy step

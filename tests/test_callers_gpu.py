@@ -1,0 +1,135 @@
+"""End-to-end runs of the caller counterparts (orient_pointcloud / orient_large / orient_simple /
+reference_orientation / dipole_api) on the reference's clouds, checked against the oracle running the
+same stages on the CPU.  GPU only."""
+import argparse
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from dipole_normal_prop_amd import (dipole_api, options, orient_large, orient_pointcloud, orient_simple,
+                                    reference_orientation, util)
+from dipole_normal_prop_amd import field_utils as fu
+from oracle import dipole_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def write_xyz(path, arr):
+    util.export_pc(torch.from_numpy(np.asarray(arr, dtype=np.float32)).transpose(0, 1), path)
+
+
+def opts_for(tmp_path, pc_path, **kw):
+    args = ["--pc", str(pc_path), "--export_dir", str(tmp_path / "out")] + [str(a) for a in kw.pop("extra", [])]
+    o = options.get_parser().parse_args(args)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    o.export_dir.mkdir(exist_ok=True, parents=True)
+    return o
+
+
+def test_orient_pointcloud_on_fandisk(dev, tmp_path):
+    """demos/fandisk.sh flags without the network: n_part 30, min 100, diffuse; compared stage by stage with
+    the oracle (same partition, same filter, same start patch)."""
+    raw = load_golden("G5_fandisk_allpairs")["raw"]
+    gen = torch.Generator().manual_seed(3)
+    flip = torch.rand(raw.shape[0], generator=gen) < 0.5
+    scr = raw.copy()
+    scr[flip.numpy(), 3:] *= -1
+    write_xyz(tmp_path / "fandisk.xyz", scr)
+    o = opts_for(tmp_path, tmp_path / "fandisk.xyz", number_parts=30, minimum_points_per_patch=100, iters=1,
+                 propagation_iters=5, diffuse=True)
+    options.export_options(o)
+    out = orient_pointcloud.run(o).cpu()
+    assert (tmp_path / "out" / "final_result.xyz").exists() and (tmp_path / "out" / "opts.txt").exists()
+    start = fu.strongest_field_propagation.last_trace["start"]
+    # oracle pipeline on the CPU with the same stages
+    pc, _ = util.Transform.trans(util.load_xyz(tmp_path / "fandisk.xyz"))
+    allp = util.divide_pc(pc[:, :3], 30, min_patch=100)
+    kept = util.fix_n_filter(pc, [p.clone() for p in allp], 0.0)
+    for _, p in kept:
+        pc[p] = util.orient_center(pc[p])
+    ref, _ = O.strongest_field_propagation(pc, kept, allp, diffuse=True, start_patch=start)
+    if O.measure_mean_potential(ref) < 0:
+        ref[:, 3:] *= -1
+    assert torch.equal(out[:, :3], ref[:, :3])
+    assert np.array_equal(((out[:, 3:] * ref[:, 3:]).sum(-1) > 0).numpy(), np.ones(len(ref), dtype=bool))
+    written = util.load_xyz(tmp_path / "out" / "final_result.xyz")
+    assert torch.allclose(written[:, :3], torch.from_numpy(raw[:, :3]), atol=1e-5)   # transform inverted on export
+    # the propagation must have recovered a consistent orientation of the CAD surface
+    agree = ((written[:, 3:] * torch.from_numpy(raw[:, 3:])).sum(-1) > 0).float().mean().item()
+    assert max(agree, 1 - agree) > 0.97
+
+
+def test_orient_large_and_dipole_api_on_fandisk(dev, tmp_path):
+    raw = load_golden("G5_fandisk_allpairs")["raw"]
+    write_xyz(tmp_path / "f.xyz", raw)
+    o = opts_for(tmp_path, tmp_path / "f.xyz", number_parts=30, minimum_points_per_patch=100)
+    torch.manual_seed(1)
+    out = orient_large.run(o).cpu()
+    start = fu.strongest_field_propagation_reps.last_trace["start"]
+    pc, _ = util.Transform.trans(util.load_xyz(tmp_path / "f.xyz", append_normals=False))
+    allp = util.divide_pc(pc[:, :3], 30, min_patch=100)
+    kept = util.fix_n_filter(pc, [p.clone() for p in allp], 0.0)
+    for _, p in kept:
+        pc[p] = util.orient_center(pc[p])
+    torch.manual_seed(1)
+    reps = []
+    for p in allp:
+        perm = torch.randperm(p.shape[0])
+        reps.append((p[perm[:500]], p[perm[500:]]))
+    ref, _ = O.strongest_field_propagation_reps(pc, reps, diffuse=True, start_patch=start)
+    if O.measure_mean_potential(ref) < 0:
+        ref[:, 3:] *= -1
+    assert np.array_equal(((out[:, 3:] * ref[:, 3:]).sum(-1) > 0).numpy(), np.ones(len(ref), dtype=bool))
+    # dipole_api.orient_large(opts) is the same pipeline behind the reference's importable name
+    o2 = dipole_api.get_parser().parse_args(["--pc", str(tmp_path / "f.xyz"), "--export_dir", str(tmp_path / "api"),
+                                             "--number_parts", "30"])
+    o2.export_dir.mkdir(exist_ok=True, parents=True)
+    torch.manual_seed(1)
+    out2 = dipole_api.orient_large(o2).cpu()
+    assert torch.equal(out2, out)
+
+
+def test_orient_simple_on_ok_subsample(dev, tmp_path):
+    """demos/ok_simple.sh (BASELINE config 1) on the 1000-point subsample of ok.xyz."""
+    g = load_golden("G8_point_propagation")
+    raw = g["raw"][g["sub_rows"]]
+    write_xyz(tmp_path / "ok.xyz", raw)
+    o = opts_for(tmp_path, tmp_path / "ok.xyz", diffuse=True)
+    out = orient_simple.run(o).cpu()
+    pc, _ = util.Transform.trans(util.load_xyz(tmp_path / "ok.xyz"))
+    ref, _ = O.strongest_field_propagation_points(pc, diffuse=True, starting_point=0)
+    if O.measure_mean_potential(ref) < 0:
+        ref[:, 3:] *= -1
+    assert torch.equal(out[:, :3], pc[:, :3]) and torch.equal(out[:, 3:], ref[:, 3:])
+
+
+def test_reference_orientation_both_forms(dev, tmp_path):
+    g = load_golden("G9_reference_field")
+    write_xyz(tmp_path / "ref.xyz", g["src"])
+    write_xyz(tmp_path / "in3.xyz", g["tgt3"])
+    write_xyz(tmp_path / "in6.xyz", g["tgt6"])
+    p = reference_orientation.get_parser()
+    out3 = reference_orientation.run(p.parse_args(["--input", str(tmp_path / "in3.xyz"), "--reference",
+                                                   str(tmp_path / "ref.xyz"), "--output", str(tmp_path / "o3.xyz")])).cpu()
+    assert np.abs(out3.numpy()[:, 3:] - g["out3"][:, 3:]).max() < 5e-5
+    out6 = reference_orientation.run(p.parse_args(["--input", str(tmp_path / "in6.xyz"), "--reference",
+                                                   str(tmp_path / "ref.xyz"), "--output", str(tmp_path / "o6.xyz")])).cpu()
+    assert np.array_equal(np.sign(out6.numpy()[:, 3:]), np.sign(g["out6"][:, 3:]))
+    assert util.load_xyz(tmp_path / "o6.xyz").shape == (10000, 6)
+
+
+def test_models_flag_is_rejected(tmp_path):
+    o = options.get_parser().parse_args(["--pc", "x.xyz", "--export_dir", str(tmp_path), "--models", "a.pt"])
+    with pytest.raises(SystemExit):
+        options.reject_models(o)
+
+
+def test_estimate_normals_counterpart(dev):
+    pc = torch.from_numpy(load_golden("G5_fandisk_allpairs")["pc"]).to(dev)
+    est = util.estimate_normals(pc[:, :3], max_nn=30)
+    cos = (est[:, 3:] * pc[:, 3:]).sum(-1).abs()
+    assert est.shape == (pc.shape[0], 6) and float((cos > 0.9).float().mean()) > 0.9

@@ -23,6 +23,7 @@ class OracleBackend:
     @staticmethod
     def slabs(work, off, idx, point_patch, b0, b1, eps):
         N = work.shape[0]
+        idx = torch.arange(N) if idx is None else idx        # None: cloud sorted by patch
         dE = torch.zeros(b1 - b0, N, 3)
         for k in range(b0, b1):
             src = idx[off[k]:off[k + 1]]
@@ -33,6 +34,7 @@ class OracleBackend:
     @staticmethod
     def interactions(dE, work, off, idx):
         P = off.shape[0] - 1
+        idx = torch.arange(work.shape[0]) if idx is None else idx
         dots = (dE.double() * work[None, :, 3:].double()).sum(-1)
         return torch.stack([torch.stack([dots[k, idx[off[j]:off[j + 1]]].sum() for j in range(P)])
                             for k in range(dE.shape[0])])
