@@ -558,15 +558,25 @@ def strongest_field_propagation_points(pts: torch.Tensor, diffuse=False, startin
             work = work.clone()
         N = work.shape[0]
         order = torch.empty(N, dtype=torch.int64, device=dev)
-        if N <= lib.dnp_point_greedy_max_points():
+        done = False
+        if N < lib.dnp_point_greedy_max_points():
+            # one persistent launch: a single workgroup up to 12 288 points, one workgroup per CU beyond
             nbytes = lib.dnp_point_greedy_workspace_bytes(N)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            backup = work.clone() if N > 12288 else None
             with torch.cuda.device(dev):
                 rc = lib.dnp_point_greedy_f32(_lib.ptr(work), N, work.stride(0), int(starting_point), 1e-6,
                                               int(bool(diffuse)), _lib.ptr(order), None, _lib.ptr(ws), nbytes,
                                               _lib.current_stream())
             _lib.check(rc)
-        else:
+            done = True
+            if backup is not None and int(ws[:4].view(torch.int32).item()) != 0:
+                # the multi-workgroup form needs every workgroup resident; if the GPU was shared and a spin
+                # timed out, redo the propagation step by step
+                print("warning: persistent per-point kernel timed out, falling back to step-wise launches")
+                work = backup
+                done = False
+        if not done:
             order = _points_stepwise(work, diffuse, int(starting_point))
         pts[:, 3:] = work[:, 3:].to(device=pts.device, dtype=pts.dtype)
         strongest_field_propagation_points.last_trace = dict(order=order)

@@ -54,7 +54,7 @@ def test_argument_validation_needs_no_device(lib):
     assert rc == -1 and b"ld_src" in lib.dnp_last_error()
     rc = lib.dnp_field_grad_f32(dummy, 4, 6, None, dummy, 4, 3, None, 1e-5, 0, dummy, 3, 0, 0, None, 0, None)
     assert rc == -3 and b"workspace" in lib.dnp_last_error()
-    rc = lib.dnp_point_greedy_f32(dummy, 10 ** 6, 6, 0, 1e-6, 0, None, None, None, 0, None)
+    rc = lib.dnp_point_greedy_f32(dummy, 2 ** 20, 6, 0, 1e-6, 0, None, None, None, 0, None)
     assert rc == -1 and b"exceeds" in lib.dnp_last_error()
     rc = lib.dnp_patch_fields_f32(dummy, 10, 6, dummy, dummy, 3, dummy, 2, 1, 1e-5, dummy, None)
     assert rc == -1

@@ -399,6 +399,42 @@ def test_G8_point_propagation(dev, tag):
     assert np.array_equal(((out[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g[f"sign_{tag}"])
 
 
+@pytest.mark.parametrize("groups", ["256", "37"])
+def test_G8_multi_workgroup_form_reproduces_the_reference_order(dev, groups, monkeypatch):
+    """The multi-workgroup persistent form (used beyond 12 288 points), forced onto ok.xyz: same 10 000-step
+    visit order and signs as the reference, for two different workgroup counts."""
+    monkeypatch.setenv("DNP_GREEDY_FORCE_MULTI", "1")
+    monkeypatch.setenv("DNP_GREEDY_GROUPS", groups)
+    g = load_golden("G8_point_propagation")
+    cloud = t(g["pc_full"])
+    pts = cloud.clone().to(dev)
+    fu.strongest_field_propagation_points(pts, diffuse=True, starting_point=0)
+    order = fu.strongest_field_propagation_points.last_trace["order"].cpu().numpy()
+    assert np.array_equal(order, g["order_full_d"])
+    assert np.array_equal(((pts.cpu()[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g["sign_full_d"])
+
+
+def test_point_propagation_beyond_single_workgroup_capacity(dev):
+    """20 000 points (> 12 288): the multi-workgroup form is selected automatically; a sphere with 30 % of
+    its normals flipped comes back consistently oriented, and two runs agree bit for bit."""
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(20000, 3, generator=gen)
+    n = x / x.norm(dim=-1, keepdim=True)
+    pc = torch.cat([n * 0.5, n], dim=1)
+    flip = torch.rand(20000, generator=gen) < 0.3
+    scr = pc.clone()
+    scr[flip, 3:] *= -1
+    a = scr.clone().to(dev)
+    fu.strongest_field_propagation_points(a, diffuse=True)
+    oa = fu.strongest_field_propagation_points.last_trace["order"].cpu()
+    assert sorted(oa.tolist()) == list(range(20000)) and int(oa[0]) == 0
+    agree = ((a.cpu()[:, 3:] * pc[:, 3:]).sum(-1) > 0).float().mean().item()
+    assert agree in (0.0, 1.0)
+    b = scr.clone().to(dev)
+    fu.strongest_field_propagation_points(b, diffuse=True)
+    assert torch.equal(a, b) and torch.equal(oa, fu.strongest_field_propagation_points.last_trace["order"].cpu())
+
+
 def test_point_propagation_stepwise_fallback_matches_kernel(dev):
     g = load_golden("G8_point_propagation")
     cloud = t(g["pc_sub1000"])[:300].clone()

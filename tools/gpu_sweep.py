@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Size sweep of the field / potential entry points (developer tool): time per call and pairs/s."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dipole_normal_prop_amd import field_utils as fu
+from tools.gpu_check import sphere
+
+dev = torch.device("cuda:0")
+def timeit(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+grid = fu.util.gen_grid().to(dev)
+for n in (1000, 3000, 11031, 30000, 100000):
+    pc = sphere(n).to(dev)
+    t = timeit(lambda: fu.field_grad(pc, pc), reps=20 if n < 50000 else 5)
+    tp = timeit(lambda: fu.potential(pc, grid))
+    t1 = timeit(lambda: fu.field_grad(pc[:400], pc))
+    print(f"N={n:6d}: field_grad NxN {t*1e6:9.1f} us ({n*n/t/1e9:7.1f} Gpairs/s) | potential Nx1000 {tp*1e6:7.1f} us "
+          f"({n*1000/tp/1e9:6.1f} Gp/s) | field_grad 400xN {t1*1e6:7.1f} us ({400*n/t1/1e9:6.1f} Gp/s)", flush=True)
