@@ -73,11 +73,18 @@ def check(rc):
         raise DnpError(f"libdnp error {rc}: {msg}")
 
 
+_device_ok = False
+
+
 def require_device():
-    lib = load()
-    if not torch.cuda.is_available() or lib.dnp_device_count() < 1:
-        raise DnpError("no HIP device visible: the dipole field kernels run on MI355X (gfx950) only; "
-                       "there is no CPU fallback")
+    """The loaded library, after checking once per process that a HIP device is visible."""
+    global _device_ok
+    lib = _lib if _lib is not None else load()
+    if not _device_ok:
+        if not torch.cuda.is_available() or lib.dnp_device_count() < 1:
+            raise DnpError("no HIP device visible: the dipole field kernels run on MI355X (gfx950) only; "
+                           "there is no CPU fallback")
+        _device_ok = True
     return lib
 
 

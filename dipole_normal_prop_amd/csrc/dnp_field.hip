@@ -12,11 +12,10 @@
 
 namespace dnp {
 
-#ifndef DNP_KT
-#define DNP_KT 2
-#endif
-constexpr int kKT = DNP_KT;               // targets per lane
-constexpr int64_t kMinChunk = 512;        // do not cut leaves into pieces shorter than this
+// shortest chunk a leaf is cut into: 64 sources for tiny source sets (latency bound: more, shorter workgroups),
+// growing to 512 so that large source sets are not shredded into hundreds of chunks per leaf
+static inline int64_t min_chunk(int64_t S) { const int64_t m = S / 64; return m < 64 ? 64 : (m > 512 ? 512 : m); }
+constexpr int64_t kTilesForKT2 = 128;     // 2 targets per lane once that still leaves >= 128 target tiles
 #ifndef DNP_WANT_BLOCKS
 #define DNP_WANT_BLOCKS 8192
 #endif
@@ -31,6 +30,7 @@ struct Plan {
     };
     std::vector<Round> rounds;
     int64_t max_chunks = 0;  // largest n_chunks over the rounds
+    int kt = 1;              // targets per lane (1 for small target sets: twice the workgroups)
 };
 
 static void split_leaves(int64_t lo, int64_t hi, int64_t max_pts, std::vector<int64_t>& cuts) {
@@ -48,7 +48,10 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
     Plan plan;
     std::vector<int64_t> cuts;  // leaf end offsets
     if (S > 0) split_leaves(0, S, max_pts, cuts);
-    const int64_t t_tiles = ceil_div(T > 0 ? T : 1, (int64_t)kBlock * kKT);
+    // small problems are latency bound: prefer many short workgroups (1 target per lane, chunks down to 64
+    // sources); large ones amortise the LDS reads over 2 targets per lane
+    plan.kt = (T >= (int64_t)kBlock * 2 * kTilesForKT2) ? 2 : 1;
+    const int64_t t_tiles = ceil_div(T > 0 ? T : 1, (int64_t)kBlock * plan.kt);
     const int64_t n_leaves = (int64_t)cuts.size();
     int64_t want = ceil_div(kWantBlocks, t_tiles);
     if (want < n_leaves) want = n_leaves;
@@ -56,6 +59,8 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
     int64_t cap = (int64_t)(kSlabCap / ((size_t)(T > 0 ? T : 1) * nc * elem));
     if (cap > kMaxChunks) cap = kMaxChunks;
     if (cap < 1) cap = 1;
+    // keep all leaves in ONE round whenever they fit: a round is two launches
+    if (n_leaves <= cap && want > cap) want = cap;
 
     Plan::Round cur;
     cur.chunk_off.push_back(0);
@@ -64,8 +69,8 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
     for (int64_t l = 0; l < n_leaves; ++l) {
         const int64_t hi = cuts[l];
         const int64_t len = hi - lo;
-        int64_t m = (want * len + S - 1) / S;           // this leaf's share of the wanted chunks
-        const int64_t m_max = len / kMinChunk > 0 ? len / kMinChunk : 1;
+        int64_t m = want * len / S;                     // this leaf's share of the wanted chunks (floor: sum <= want)
+        const int64_t m_max = len / min_chunk(S) > 0 ? len / min_chunk(S) : 1;
         if (m > m_max) m = m_max;
         if (m > cap) m = cap;
         if (m < 1) m = 1;
@@ -114,7 +119,15 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs<F> a) {
     double total = 0.0;
     for (int l = 0; l < a.n_leaves; ++l) {
         double s = 0.0;
-        for (int ch = a.leaf_first[l]; ch < a.leaf_first[l + 1]; ++ch) s += a.partial[ch * stride + i];
+        const int c1 = a.leaf_first[l + 1];
+        // 8 independent loads in flight, added in chunk order (the sum does not depend on the batching)
+        for (int ch = a.leaf_first[l]; ch < c1; ch += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (ch + u < c1) ? a.partial[(int64_t)(ch + u) * stride + i] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
         const F f = (F)s;
         // E_total[E_total.isinf()] = 0; E_total[E_total.isnan()] = 0   (per leaf, per component)
         total += (__builtin_isfinite(f)) ? (double)f : 0.0;
@@ -160,7 +173,7 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
         set_error("workspace of %zu bytes required, %zu given", need, workspace ? workspace_bytes : (size_t)0);
         return DNP_EWORKSPACE;
     }
-    const int64_t t_tiles = ceil_div(T, (int64_t)kBlock * kKT);
+    const int64_t t_tiles = ceil_div(T, (int64_t)kBlock * plan.kt);
     DNP_REQUIRE(t_tiles <= INT32_MAX, "T too large");
 
     bool first = true;
@@ -171,17 +184,27 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
         pa.tgt = tgt; pa.ld_tgt = ld_tgt; pa.tgt_idx = tgt_idx; pa.T = T;
         pa.chunk_off_dev = nullptr; pa.chunk_base = 0; pa.tgt_group = nullptr;
         pa.eps = eps; pa.partial = (double*)workspace;
+        // one chunk that is also the only leaf of the only round: the pair kernel writes the final rows
+        const bool direct = plan.rounds.size() == 1 && n_chunks == 1;
+        pa.out = direct ? out : nullptr; pa.ld_out = ld_out; pa.out_scatter = out_scatter; pa.accumulate = accumulate;
         for (int i = 0; i <= n_chunks; ++i) pa.chunk_off[i] = r.chunk_off[i];
         const dim3 grid((unsigned)t_tiles, (unsigned)n_chunks);
         // eps > 0 (what every caller of the reference passes): the short chain; otherwise the explicit one
         const int variant = (MODE != kField) ? kFast : (eps > F(0) ? kFast : (eps == F(0) ? kNanCoinc : kRobust));
-        if (variant == kFast)
-            hipLaunchKernelGGL((pair_kernel<F, double, MODE, kKT, kFast>), grid, dim3(kBlock), 0, stream, pa);
-        else if (variant == kNanCoinc)
-            hipLaunchKernelGGL((pair_kernel<F, double, MODE, kKT, kNanCoinc>), grid, dim3(kBlock), 0, stream, pa);
-        else
-            hipLaunchKernelGGL((pair_kernel<F, double, MODE, kKT, kRobust>), grid, dim3(kBlock), 0, stream, pa);
+#define DNP_LAUNCH_PAIR(KT, V) \
+    hipLaunchKernelGGL((pair_kernel<F, double, MODE, KT, V>), grid, dim3(kBlock), 0, stream, pa)
+        if (plan.kt == 2) {
+            if (variant == kFast) DNP_LAUNCH_PAIR(2, kFast);
+            else if (variant == kNanCoinc) DNP_LAUNCH_PAIR(2, kNanCoinc);
+            else DNP_LAUNCH_PAIR(2, kRobust);
+        } else {
+            if (variant == kFast) DNP_LAUNCH_PAIR(1, kFast);
+            else if (variant == kNanCoinc) DNP_LAUNCH_PAIR(1, kNanCoinc);
+            else DNP_LAUNCH_PAIR(1, kRobust);
+        }
+#undef DNP_LAUNCH_PAIR
         DNP_CHECK_HIP(hipGetLastError());
+        if (direct) break;
 
         ReduceArgs<F> ra{};
         ra.partial = (const double*)workspace; ra.T = T; ra.tgt_idx = tgt_idx; ra.out = out; ra.ld_out = ld_out;

@@ -361,9 +361,14 @@ int dnp_point_greedy_f32(float* pts, int64_t N, int64_t ld_pts, int64_t start, f
     DNP_REQUIRE(N < (int64_t)kIdxMask, "N=%lld exceeds the %u points of the persistent per-point kernel",
                 (long long)N, kIdxMask - 1);
     hipStream_t st = (hipStream_t)stream;
-    // DNP_GREEDY_FORCE_MULTI=1 routes small clouds through the multi-workgroup form too (tests)
+    // Form selection: one workgroup keeps everything in registers but pays ~0.9 us per point-per-lane and step
+    // (IEEE div/sqrt chain); one workgroup per CU pays ~7 us per step for the granule all-gather.  Measured
+    // crossover ~3000 points (ok.xyz, 10 000 points: 20.6 vs 7.0 us/step).  DNP_GREEDY_FORCE_MULTI=1 / =0
+    // force the multi- / single-workgroup form where it applies (tests).
     const char* force = getenv("DNP_GREEDY_FORCE_MULTI");
-    const bool multi = N > (int64_t)kGreedyThreads * 24 || (force && force[0] == '1');
+    bool multi = N > 2048;
+    if (force && force[0] == '1') multi = true;
+    if (force && force[0] == '0' && N <= (int64_t)kGreedyThreads * 24) multi = false;
     if (!multi) {
 #define DNP_LAUNCH_GREEDY(P)                                                                                   \
     hipLaunchKernelGGL((point_greedy_kernel<P>), dim3(1), dim3(kGreedyThreads), 0, st, pts, N, ld_pts, (int)start, \

@@ -32,7 +32,7 @@ namespace dnp {
 constexpr int kBlock = 256;       // threads per workgroup (4 waves, one per SIMD)
 constexpr int kFlush = 128;       // sources between two spills of the fp32 sums into the fp64 sums
 constexpr int kSets = 4;          // interleaved fp32 accumulator sets (chain length kFlush / kSets)
-constexpr int kMaxChunks = 128;   // by-value chunk table entries per launch
+constexpr int kMaxChunks = 512;   // by-value chunk table entries per launch (2 KB of kernarg)
 
 enum PairMode { kField = 0, kPotential = 1 };
 
@@ -50,6 +50,11 @@ struct PairArgs {
     const int64_t* tgt_group;      // per target-row group id; rows whose group == chunk id get 0
     F eps;
     PT* partial;             // [gridDim.y][T][NC]; PT = double keeps the chunk sums unrounded
+    // direct epilogue (one chunk == one leaf): write the final rows here instead of a partial slab
+    F* out;                  // nullptr = write `partial`
+    int64_t ld_out;
+    int out_scatter;         // row = tgt_idx[t]
+    int accumulate;          // out += result
     int32_t chunk_off[kMaxChunks + 1];  // by-value CSR offsets when chunk_off_dev == nullptr
 };
 
@@ -266,11 +271,22 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
         if (t < a.T) {
             bool excluded = false;
             if (a.tgt_group) excluded = (a.tgt_group[trow[k]] == chunk_id);
-            PT* o = a.partial + ((int64_t)chunk * a.T + t) * NC;
+            if (a.out) {
+                // single chunk, single leaf: the second pass would only filter and copy - do it here
+                F* o = a.out + (a.out_scatter ? trow[k] : t) * a.ld_out;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const double v = (MODE == kField) ? -acc[k][c] : acc[k][c];
-                o[c] = excluded ? PT(0) : (PT)v;
+                for (int c = 0; c < NC; ++c) {
+                    F v = (F)((MODE == kField) ? -acc[k][c] : acc[k][c]);
+                    if (!__builtin_isfinite(v)) v = F(0);            // field_utils.py:110-115 / :53-54
+                    o[c] = a.accumulate ? (F)(o[c] + v) : v;
+                }
+            } else {
+                PT* o = a.partial + ((int64_t)chunk * a.T + t) * NC;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const double v = (MODE == kField) ? -acc[k][c] : acc[k][c];
+                    o[c] = excluded ? PT(0) : (PT)v;
+                }
             }
         }
     }

@@ -14,6 +14,8 @@ Reference lines each function mirrors are cited in its docstring.
 """
 from typing import List, Optional, Tuple
 
+import threading
+
 import numpy as np
 import torch
 
@@ -56,6 +58,38 @@ def _stage(t: torch.Tensor, dev: torch.device, dtype: torch.dtype) -> torch.Tens
     return t
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def _on_device(dev):
+    """torch.cuda.device(dev) only when dev is not already current (the context manager costs ~10 us)."""
+    return _NULL if dev.index is None or dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+
+_tls = threading.local()
+
+
+def _workspace(nbytes: int, dev: torch.device) -> torch.Tensor:
+    """Scratch for one launch sequence, cached per (thread, device, stream): work on one stream is
+    ordered, so the next call on that stream may overwrite it; other streams / threads get their own."""
+    cache = getattr(_tls, "ws", None)
+    if cache is None:
+        cache = _tls.ws = {}
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = cache[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+    return buf
+
+
 def _ld(t: torch.Tensor) -> int:
     return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
 
@@ -80,14 +114,14 @@ def _pairs_into(kind: str, src, src_idx, tgt, tgt_idx, eps, max_pts, out, out_sc
         nbytes = lib.dnp_field_grad_workspace_bytes(S, T, max_pts)
     else:
         nbytes = lib.dnp_potential_workspace_bytes(S, T, max_pts)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=src.device)
-    with torch.cuda.device(src.device):
+    ws = _workspace(nbytes, src.device)
+    with _on_device(src.device):
         stream = _lib.current_stream()
         if kind == "field":
             fn = lib.dnp_field_grad_f64 if f64 else lib.dnp_field_grad_f32
             rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(src_idx), _lib.ptr(tgt), T, _ld(tgt), _lib.ptr(tgt_idx),
                     float(eps), int(max_pts), _lib.ptr(out), out.stride(0) if out.shape[0] > 1 else 3,
-                    int(bool(out_scatter)), int(bool(accumulate)), _lib.ptr(ws), nbytes, stream)
+                    int(bool(out_scatter)), int(bool(accumulate)), _lib.ptr(ws), ws.numel(), stream)
         else:
             fn = lib.dnp_potential_f64 if f64 else lib.dnp_potential_f32
             rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(src_idx), _lib.ptr(tgt), T, _ld(tgt), _lib.ptr(tgt_idx),
@@ -560,10 +594,10 @@ def strongest_field_propagation_points(pts: torch.Tensor, diffuse=False, startin
         order = torch.empty(N, dtype=torch.int64, device=dev)
         done = False
         if N < lib.dnp_point_greedy_max_points():
-            # one persistent launch: a single workgroup up to 12 288 points, one workgroup per CU beyond
+            # one persistent launch: a single workgroup up to 2048 points, one workgroup per CU beyond
             nbytes = lib.dnp_point_greedy_workspace_bytes(N)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            backup = work.clone() if N > 12288 else None
+            backup = work.clone() if N > 2048 else None   # the multi-workgroup form may time out on a shared GPU
             with torch.cuda.device(dev):
                 rc = lib.dnp_point_greedy_f32(_lib.ptr(work), N, work.stride(0), int(starting_point), 1e-6,
                                               int(bool(diffuse)), _lib.ptr(order), None, _lib.ptr(ws), nbytes,

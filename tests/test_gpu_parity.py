@@ -381,11 +381,13 @@ def test_G7_reps_propagation(dev, tag):
 
 
 @pytest.mark.parametrize("tag", ["sub1000_n", "sub1000_d", "full_n", "full_d"])
-def test_G8_point_propagation(dev, tag):
+def test_G8_point_propagation(dev, tag, monkeypatch):
     """BASELINE config 1: ok.xyz per-point propagation (10 000 points) and a 1000-point subsample:
     the complete visit order and every final sign of the reference."""
     g = load_golden("G8_point_propagation")
     name, dflag = tag.split("_")
+    if tag == "full_n":
+        monkeypatch.setenv("DNP_GREEDY_FORCE_MULTI", "0")           # the single-workgroup form on the full cloud
     cloud = t(g[f"pc_{name}"])
     pts = cloud.clone().to(dev)
     ret = fu.strongest_field_propagation_points(pts, diffuse=(dflag == "d"), starting_point=0)

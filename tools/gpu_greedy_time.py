@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Timing of the per-point greedy propagation forms (developer tool)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from dipole_normal_prop_amd import field_utils as fu
+from conftest import load_golden
+from tools.gpu_check import sphere
+
+dev = torch.device("cuda:0")
+def run(pc, label):
+    a = pc.clone().to(dev)
+    fu.strongest_field_propagation_points(a, diffuse=True); torch.cuda.synchronize()
+    a = pc.clone().to(dev); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fu.strongest_field_propagation_points(a, diffuse=True); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = pc.shape[0]
+    print(f"{label}: N={n} {dt*1e3:.1f} ms -> {dt/n*1e6:.2f} us/step, {n*n/dt/1e9:.2f} Gpairs/s", flush=True)
+
+ok = torch.from_numpy(load_golden("G8_point_propagation")["pc_full"])
+run(ok, "ok.xyz single-workgroup")
+os.environ["DNP_GREEDY_FORCE_MULTI"] = "1"
+run(ok, "ok.xyz multi-workgroup ")
+del os.environ["DNP_GREEDY_FORCE_MULTI"]
+run(sphere(30000), "sphere multi-workgroup")
+run(sphere(100000), "sphere multi-workgroup")
+b = ok[:2000].clone().to(dev)
+t0 = time.perf_counter(); fu._points_stepwise(b, True, 0); torch.cuda.synchronize()
+print(f"step-wise fallback: N=2000 {(time.perf_counter()-t0)*1e3:.1f} ms -> {(time.perf_counter()-t0)/2000*1e6:.1f} us/step")
