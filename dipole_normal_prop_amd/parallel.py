@@ -103,10 +103,7 @@ def sharded_patch_propagation(pts: torch.Tensor, patches, all_patches, diffuse=F
         flip[inpatch] = sig[point_patch[inpatch]]
         work[:, 3:] = work[:, 3:] * flip[:, None]
         if diffuse:
-            for _, patch in patches:
-                p = patch.to(dev)
-                s = ((E[p] * work[p, 3:]).sum(dim=-1) > 0).float() * 2 - 1
-                work[p, 3:] = work[p, 3:] * s[:, None]
+            fu._diffuse_sign_pass(work, E, [patch for _, patch in patches])
         if w is not None:
             work[:, 3:] = work[:, 3:] / w[:, None]
         pts[:, 3:] = work[:, 3:].to(device=pts.device, dtype=pts.dtype)
