@@ -56,8 +56,17 @@ def load():
         if _lib is not None:
             return _lib
         if not os.path.exists(LIB_PATH):
-            raise DnpError(f"{LIB_PATH} not found - build it with `python -m dipole_normal_prop_amd.build` "
-                           "(there is no CPU fallback for the field kernels)")
+            # a fresh checkout: compile the HIP library once (hipcc is part of the ROCm image); there is no
+            # CPU fallback, so a failed build is an error, not a degradation
+            if "DNP_LIB" in os.environ:
+                raise DnpError(f"DNP_LIB={LIB_PATH} does not exist")
+            try:
+                from . import build as _build
+                _build.build(verbose=False)
+            except Exception as exc:
+                raise DnpError(f"{LIB_PATH} not found and building it failed ({exc}); run "
+                               "`python -m dipole_normal_prop_amd.build` - there is no CPU fallback for the "
+                               "field kernels") from exc
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
