@@ -170,7 +170,7 @@ def main():
     launch_pairs = float((sizes[p_lo:p_hi] * N_POINTS).sum())
     tflops = launch_pairs * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
     algo_bytes = 36.0 * N_POINTS + 12.0 * N_POINTS * (p_hi - p_lo)   # cloud read once + [K,N,3] slab written once
-    roofline = {"bound": "valu", "kernel": "pair_kernel<float,field,KT=2>", "achieved": tflops,
+    roofline = {"bound": "valu", "kernel": "pair_kernel<float,float,field,KT=4,kFast>", "achieved": tflops,
                 "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VALU_PEAK_TFLOPS,
                 "traffic": None, "launch_ms": k_ms, "flop_per_pair": FLOP_PER_PAIR,
                 "pairs_per_launch": launch_pairs,

@@ -14,8 +14,12 @@ namespace dnp {
 
 // shortest chunk a leaf is cut into: 64 sources for tiny source sets (latency bound: more, shorter workgroups),
 // growing to 512 so that large source sets are not shredded into hundreds of chunks per leaf
-static inline int64_t min_chunk(int64_t S) { const int64_t m = S / 64; return m < 64 ? 64 : (m > 512 ? 512 : m); }
-constexpr int64_t kTilesForKT2 = 128;     // 2 targets per lane once that still leaves >= 128 target tiles
+#ifndef DNP_MINCHUNK_CAP
+#define DNP_MINCHUNK_CAP 512
+#endif
+static inline int64_t min_chunk(int64_t S) { const int64_t m = S / 64; return m < 64 ? 64 : (m > DNP_MINCHUNK_CAP ? DNP_MINCHUNK_CAP : m); }
+constexpr int kKTLarge = 4;                // targets per lane for large target sets (swept: 4 x 2 accumulator sets)
+constexpr int64_t kTilesForLarge = 64;     // ... used once that still leaves >= 64 target tiles
 #ifndef DNP_WANT_BLOCKS
 #define DNP_WANT_BLOCKS 8192
 #endif
@@ -50,7 +54,7 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
     if (S > 0) split_leaves(0, S, max_pts, cuts);
     // small problems are latency bound: prefer many short workgroups (1 target per lane, chunks down to 64
     // sources); large ones amortise the LDS reads over 2 targets per lane
-    plan.kt = (T >= (int64_t)kBlock * 2 * kTilesForKT2) ? 2 : 1;
+    plan.kt = (T >= (int64_t)kBlock * kKTLarge * kTilesForLarge) ? kKTLarge : 1;
     const int64_t t_tiles = ceil_div(T > 0 ? T : 1, (int64_t)kBlock * plan.kt);
     const int64_t n_leaves = (int64_t)cuts.size();
     int64_t want = ceil_div(kWantBlocks, t_tiles);
@@ -193,10 +197,10 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
         const int variant = (MODE != kField) ? kFast : (eps > F(0) ? kFast : (eps == F(0) ? kNanCoinc : kRobust));
 #define DNP_LAUNCH_PAIR(KT, V) \
     hipLaunchKernelGGL((pair_kernel<F, double, MODE, KT, V>), grid, dim3(kBlock), 0, stream, pa)
-        if (plan.kt == 2) {
-            if (variant == kFast) DNP_LAUNCH_PAIR(2, kFast);
-            else if (variant == kNanCoinc) DNP_LAUNCH_PAIR(2, kNanCoinc);
-            else DNP_LAUNCH_PAIR(2, kRobust);
+        if (plan.kt == kKTLarge) {
+            if (variant == kFast) DNP_LAUNCH_PAIR(kKTLarge, kFast);
+            else if (variant == kNanCoinc) DNP_LAUNCH_PAIR(kKTLarge, kNanCoinc);
+            else DNP_LAUNCH_PAIR(kKTLarge, kRobust);
         } else {
             if (variant == kFast) DNP_LAUNCH_PAIR(1, kFast);
             else if (variant == kNanCoinc) DNP_LAUNCH_PAIR(1, kNanCoinc);

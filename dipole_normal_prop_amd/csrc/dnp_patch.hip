@@ -7,7 +7,7 @@
 namespace dnp {
 
 #ifndef DNP_KT
-#define DNP_KT 2
+#define DNP_KT 4
 #endif
 constexpr int kPatchKT = DNP_KT;
 

@@ -2,7 +2,9 @@
 // potential entry points (dnp_field.hip) and the batched per-patch entry point (dnp_patch.hip).
 //
 // Work decomposition
-//   grid.x = target tiles (BLOCK threads x KT targets per lane), grid.y = source chunks.
+//   grid.x = target tiles (BLOCK threads x KT targets per lane; KT = 4 for large target sets, 1 for small
+//   ones - swept on gfx950: 4 targets x 2 accumulator sets (134 VGPRs, 3 waves/SIMD) beats 2 x 4 (120 VGPRs,
+//   4 waves) by 2 %, 6 x 2 and 4 x 4 lose to register pressure), grid.y = source chunks.
 //   A block streams its chunk's sources through LDS in tiles of BLOCK rows (double-buffered:
 //   the next tile's global loads are in flight while the current tile is consumed) and every
 //   lane accumulates KT targets in registers.  All 64 lanes of a wave read the SAME LDS
@@ -18,7 +20,7 @@
 // issues at 2 cycles per wave64, v_pk_fma_f32 at 4 (no gain from packing), v_rsq/v_rcp/v_sqrt at
 // ~7.3, so the loop costs ~26.3 issue slots per pair and the FP32 vector ALU is the roofline.
 //
-// Accumulation: fp32 inside a run of kFlush sources, spread over kSets interleaved accumulator
+// Accumulation: fp32 inside a run of kFlush = 64 sources, spread over kSets = 2 interleaved accumulator
 // sets (chains of 32 adds), fp64 across runs (one cvt+fma per run, ~1 % of the issue slots) - the
 // reference's own sum is a cascade sum (torch CPU); a plain fp32 chain over 10^5 terms would not
 // stay within 1e-5 of it, and with 128-long chains the accumulation error still dominated the
@@ -30,8 +32,18 @@
 namespace dnp {
 
 constexpr int kBlock = 256;       // threads per workgroup (4 waves, one per SIMD)
-constexpr int kFlush = 128;       // sources between two spills of the fp32 sums into the fp64 sums
-constexpr int kSets = 4;          // interleaved fp32 accumulator sets (chain length kFlush / kSets)
+#ifndef DNP_FLUSH
+#define DNP_FLUSH 64
+#endif
+constexpr int kFlush = DNP_FLUSH;  // sources between two spills of the fp32 sums into the fp64 sums
+#ifndef DNP_SETS
+#define DNP_SETS 2
+#endif
+constexpr int kSets = DNP_SETS;   // interleaved fp32 accumulator sets (chain length kFlush / kSets); 2 or 4
+#ifndef DNP_UNROLL
+#define DNP_UNROLL DNP_SETS
+#endif
+constexpr int kUnroll = DNP_UNROLL;  // sources per inner-loop iteration (multiple of kSets; source u -> set u % kSets)
 constexpr int kMaxChunks = 512;   // by-value chunk table entries per launch (2 KB of kernarg)
 
 enum PairMode { kField = 0, kPotential = 1 };
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
         const int64_t tile_s = s_begin + it * kBlock;
         if (it + 1 < n_tiles) load_row(tile_s + kBlock + tid);   // in flight during the compute below
         int n_here = (int)((s_end - tile_s) < kBlock ? (s_end - tile_s) : kBlock);
-        n_here = (n_here + 3) & ~3;                                // rows past s_end are padding rows
+        n_here = (n_here + 3) & ~3;                                // rows past s_end are padding rows (kUnroll | 4)
 
         for (int j0 = 0; j0 < n_here; j0 += kFlush) {
             const int j1 = (j0 + kFlush < n_here) ? j0 + kFlush : n_here;   // multiples of kSets
@@ -219,24 +231,27 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
                     for (int k = 0; k < KT; ++k)
 #pragma unroll
                         for (int c = 0; c < 3; ++c) A[u][k][c] = B[u][k][c] = F(0);
-                for (int j = j0; j < j1; j += kSets) {
+                for (int j = j0; j < j1; j += kUnroll) {
 #pragma unroll
-                    for (int u = 0; u < kSets; ++u) {
+                    for (int u = 0; u < kUnroll; ++u) {
                         const Vec4<F> s0 = lds[buf][j + u][0];
                         const Vec4<F> s1 = lds[buf][j + u][1];
+                        constexpr int kS = kSets;
 #pragma unroll
                         for (int k = 0; k < KT; ++k)
                             pair_field<F, V>(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx[k], ty[k], tz[k], a.eps,
-                                                     A[u][k][0], A[u][k][1], A[u][k][2], B[u][k][0], B[u][k][1],
-                                                     B[u][k][2]);
+                                             A[u % kS][k][0], A[u % kS][k][1], A[u % kS][k][2], B[u % kS][k][0],
+                                             B[u % kS][k][1], B[u % kS][k][2]);
                     }
                 }
 #pragma unroll
                 for (int k = 0; k < KT; ++k)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        const F as = (A[0][k][c] + A[1][k][c]) + (A[2][k][c] + A[3][k][c]);
-                        const F bs = (B[0][k][c] + B[1][k][c]) + (B[2][k][c] + B[3][k][c]);
+                        const F as = (kSets == 4) ? (A[0][k][c] + A[1][k][c]) + (A[2 % kSets][k][c] + A[3 % kSets][k][c])
+                                                  : (A[0][k][c] + A[1][k][c]);
+                        const F bs = (kSets == 4) ? (B[0][k][c] + B[1][k][c]) + (B[2 % kSets][k][c] + B[3 % kSets][k][c])
+                                                  : (B[0][k][c] + B[1][k][c]);
                         acc[k][c] += 3.0 * (double)as - (double)bs;
                     }
             } else {
@@ -256,7 +271,9 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < KT; ++k) acc[k][0] += (double)((P[0][k] + P[1][k]) + (P[2][k] + P[3][k]));
+                for (int k = 0; k < KT; ++k)
+                    acc[k][0] += (kSets == 4) ? (double)((P[0][k] + P[1][k]) + (P[2 % kSets][k] + P[3 % kSets][k]))
+                                              : (double)(P[0][k] + P[1][k]);
             }
         }
         if (it + 1 < n_tiles) store_row(buf ^ 1);
