@@ -95,6 +95,26 @@ def test_orient_large_and_dipole_api_on_fandisk(dev, tmp_path):
     assert torch.equal(out2, out)
 
 
+def test_orient_large_at_baseline_size(dev, tmp_path):
+    """BASELINE config 3 stand-in (lion.xyz is not in the reference tree): demos/lion.sh flags (number_parts 41,
+    minimum_points_per_patch 100) on the 100 000-point sphere with half of the normals flipped in the file.
+    orient_center + the representative propagation + the global potential fix must bring every normal back."""
+    from test_oracle_golden import sphere100k
+    pc = sphere100k()
+    gen = torch.Generator().manual_seed(5)
+    flip = torch.rand(pc.shape[0], generator=gen) < 0.5
+    scr = pc.clone()
+    scr[flip, 3:] *= -1
+    write_xyz(tmp_path / "sphere.xyz", scr.numpy())
+    o = opts_for(tmp_path, tmp_path / "sphere.xyz", number_parts=41, minimum_points_per_patch=100)
+    out = orient_large.run(o).cpu()
+    tr = fu.strongest_field_propagation_reps.last_trace
+    assert len(tr["order"]) > 400                                        # several hundred patches
+    outward = ((out[:, 3:] * out[:, :3]).sum(-1) > 0).float().mean().item()
+    assert outward == 1.0
+    assert (tmp_path / "out" / "final_result.xyz").stat().st_size > 5_000_000
+
+
 def test_orient_simple_on_ok_subsample(dev, tmp_path):
     """demos/ok_simple.sh (BASELINE config 1) on the 1000-point subsample of ok.xyz."""
     g = load_golden("G8_point_propagation")
