@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 N_POINTS = 100_000
 N_PATCHES = 256
-FLOP_PER_PAIR = 33            # 3 sub, 5 d2, rsq, d, fma, rcp, 5 p.r, 3 coefficient, 12 accumulate
+FLOP_PER_PAIR = 33            # 3 sub, 5 r.r, 5 p.r, sqrt, 2 fma (4), rcp, 2 mul, 12 accumulate
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md (= the dense f32 MFMA peak)
 HBM_PEAK_GBS = 8000.0
 

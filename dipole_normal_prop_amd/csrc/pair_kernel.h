@@ -9,16 +9,18 @@
 //   the next tile's global loads are in flight while the current tile is consumed) and every
 //   lane accumulates KT targets in registers.  All 64 lanes of a wave read the SAME LDS
 //   address per source (hardware broadcast, conflict-free): one ds_read_b128 + one ds_read_b64
-//   feed KT x 28 VALU issue slots.  Output: partial[chunk][target][NC], reduced by a second,
+//   feed KT x 21 VALU instructions.  Output: partial[chunk][target][NC], reduced by a second,
 //   tiny kernel - deterministic (no float atomics), and the natural place for the reference's
-//   per-leaf Inf/NaN filter (field_utils.py:110-115).
+//   per-leaf Inf/NaN filter (field_utils.py:110-115) - or, when the plan is a single chunk, the final
+//   rows directly (a.out).
 //
 // Arithmetic per pair (field mode): 19 full-rate + 2 quarter-rate (v_sqrt, v_rcp) VALU instructions
 //   r = x_s - x_t; d2 = r.r; w = 1/(|r|^3 + eps); a = (p.r) w / |r|^2;  A += a*r;  B += w*p;  E = -(3A - B)
 // which is field_utils.py:96-109 with r^ = r/|r| folded in (see pair_field for the exact chain and
-// for how |r| == 0 contributes exactly 0).  Measured on gfx950 (tools/ubench_valu.hip): v_fma_f32
-// issues at 2 cycles per wave64, v_pk_fma_f32 at 4 (no gain from packing), v_rsq/v_rcp/v_sqrt at
-// ~7.3, so the loop costs ~26.3 issue slots per pair and the FP32 vector ALU is the roofline.
+// for how |r| == 0 contributes exactly 0).  Measured on gfx950 (tools/ubench_*.hip, profiles/r01_ubench_*):
+// v_fma_f32 issues at 2.2 cycles per wave64, v_pk_fma_f32 at 4.1 (no gain from packing), v_rsq/v_rcp/v_sqrt
+// at 8 back to back and ~13 when mixed with FMAs, so the loop costs ~65-70 cycles per 64 pairs per SIMD and
+// the FP32 vector ALU is the roofline (DESIGN.md section 4 lists the alternatives that were measured).
 //
 // Accumulation: fp32 inside a run of kFlush = 64 sources, spread over kSets = 2 interleaved accumulator
 // sets (chains of 32 adds), fp64 across runs (one cvt+fma per run, ~1 % of the issue slots) - the

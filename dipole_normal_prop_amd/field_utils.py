@@ -375,9 +375,12 @@ def _batched_patch_propagation(work: torch.Tensor, patches: List[torch.Tensor], 
                                eps: float = 1e-5, want_E: bool = True, shard=None, backend=_HipBackend):
     """Core of the batched drivers on a device cloud `work[N,6]` (normals already weight-scaled).
 
-    Returns (order, sigma, chosen, E) where E[N,3] is the accumulated field of the diffuse form
-    (None unless want_E).  `shard` = (rank, world, gather_fn): patches are split over ranks, each
-    rank computes its slabs and W rows, gather_fn(all rows) returns the full W on every rank."""
+    Returns (order, sigma, chosen, E, point_patch): E[N,3] is this rank's part of the accumulated field of
+    the diffuse form in the caller's point order (None unless want_E and diffuse), point_patch[N] the patch
+    id per point (-1 = in no patch).  `shard` = (rank, world, gather_fn): patches are split over ranks in
+    contiguous size-balanced blocks, each rank computes its slabs and W rows, gather_fn(rows, bounds)
+    returns the full W on every rank.  `backend` supplies slabs / interactions / combine - the HIP entry
+    points, or an oracle-backed stand-in in the multi-process CPU tests (plumbing only)."""
     dev = work.device
     N, P = work.shape[0], len(patches)
     off, idx = _csr(patches, dev)

@@ -13,7 +13,7 @@ partial fields.  No other collective is on the path.
 
 Reference lines: the loop being distributed is field_utils.py:308-335.
 """
-from typing import Callable, Optional
+from typing import Optional
 
 import numpy as np
 import torch
