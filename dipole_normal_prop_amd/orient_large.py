@@ -34,8 +34,7 @@ def run(opts):
         patch_indices = util.fix_n_filter(input_pc, patch_indices, opts.curvature_threshold)
     print(f'number of patches {len(patch_indices)}/{len(all_patches_indices)}')
     with MyTimer('orient center'):
-        for _, p in patch_indices:
-            input_pc[p] = util.orient_center(input_pc[p])
+        util.orient_center_patches(input_pc, [p for _, p in patch_indices])
     with MyTimer('find reps'):
         represent = []
         for p in all_patches_indices:

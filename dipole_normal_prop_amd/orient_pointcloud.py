@@ -33,8 +33,7 @@ def run(opts):
         patch_indices = util.fix_n_filter(input_pc, patch_indices, opts.curvature_threshold)
     print(f'number of patches {len(patch_indices)}')
     with MyTimer('orient center'):
-        for _, p in patch_indices:
-            input_pc[p] = util.orient_center(input_pc[p])
+        util.orient_center_patches(input_pc, [p for _, p in patch_indices])
     pc_probs = torch.ones_like(input_pc[:, 0])
 
     def propagate():

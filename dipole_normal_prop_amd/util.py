@@ -47,9 +47,37 @@ def export_pc(pc: torch.Tensor, dest) -> None:
         fh.write(text)
 
 
+def _xyz_fast(txt: str, append_normals: bool):
+    """Vectorised parse for the regular case - every non-empty line has the same number (3 or 6) of
+    single-space separated numbers and there is no 'nan' anywhere.  Returns None when the text is not of
+    that form; the caller then takes the line-by-line path, which defines the semantics (blank lines are
+    skipped there as well: they split into one token)."""
+    if "nan" in txt or "\t" in txt:
+        return None
+    rows = [ln for ln in (raw.strip() for raw in txt.split("\n")) if ln]
+    if not rows:
+        return None
+    ncol = rows[0].count(" ") + 1
+    if ncol not in (3, 6) or any(ln.count(" ") != ncol - 1 for ln in rows):
+        return None
+    try:
+        vals = np.array(" ".join(rows).split(" "), dtype=np.float64)    # float(): correctly rounded, as float(x)
+    except ValueError:
+        return None
+    if vals.size != len(rows) * ncol:
+        return None
+    arr = vals.reshape(len(rows), ncol).astype(np.float32)
+    if ncol == 3 and append_normals:
+        arr = np.concatenate([arr, np.zeros((len(rows), 3), dtype=np.float32)], axis=1)
+    return torch.from_numpy(arr)
+
+
 def xyz2tensor(txt: str, append_normals: bool = True) -> torch.Tensor:
     """Parse '.xyz' text: space separated, 3 or 6 columns per line; lines containing 'nan' are
     dropped; 3-column lines get zero normals appended when append_normals."""
+    fast = _xyz_fast(txt, append_normals)
+    if fast is not None:
+        return fast
     rows = []
     for line in txt.split("\n"):
         line = line.strip()
@@ -114,44 +142,40 @@ class Transform:
 
 
 # ---- voxel partition ---------------------------------------------------------------------------
-def _axis_bins(x: torch.Tensor, n_part: int, ranges) -> np.ndarray:
+def _axis_bins(x: torch.Tensor, n_part: int, ranges) -> torch.Tensor:
     """Bin of every coordinate under the reference's test  lo_i < x <= hi_i  with
     lo_i = edge*i + ranges[0], hi_i = lo_i + edge (python doubles compared against the float32
-    column, i.e. rounded to float32 first), i = 0..n_part.  -1 = in no bin."""
+    column, i.e. rounded to float32 first), i = 0..n_part.  -1 = in no bin.  Runs on x's device."""
     edge = (ranges[1] - ranges[0]) / n_part
     lo64 = np.array([edge * i + ranges[0] for i in range(n_part + 1)], dtype=np.float64)
     hi64 = lo64 + edge
-    xv = x.detach().cpu().numpy()
-    lo = lo64.astype(xv.dtype)
-    hi = hi64.astype(xv.dtype)
-    cand = np.searchsorted(lo, xv, side="left") - 1          # largest i with lo_i < x
+    lo = torch.from_numpy(lo64).to(device=x.device, dtype=x.dtype)
+    hi = torch.from_numpy(hi64).to(device=x.device, dtype=x.dtype)
+    cand = torch.searchsorted(lo, x.contiguous(), right=False) - 1     # largest i with lo_i < x
     ok = cand >= 0
-    cand_c = np.clip(cand, 0, n_part)
-    ok &= xv <= hi[cand_c]
-    return np.where(ok, cand_c, -1)
+    cand_c = cand.clamp(0, n_part)
+    ok &= x <= hi[cand_c]
+    return torch.where(ok, cand_c, torch.full_like(cand_c, -1))
 
 
 def _divide_pc(pc_in: torch.Tensor, n_part: int, ranges=(-1.5, 1.5), min_patch: int = 0):
     """Voxel partition: returns (indices, ijk) with one entry per non-empty cell, cells in
     lexicographic (i, j, k) order and point indices ascending inside a cell - the order the
-    reference's triple loop produces."""
+    reference's triple loop produces.  Binning, sorting and splitting run on pc_in's device."""
     bx = _axis_bins(pc_in[:, 0], n_part, ranges)
     by = _axis_bins(pc_in[:, 1], n_part, ranges)
     bz = _axis_bins(pc_in[:, 2], n_part, ranges)
     inside = (bx >= 0) & (by >= 0) & (bz >= 0)
     m = n_part + 1
-    key = (bx.astype(np.int64) * m + by) * m + bz
-    pts = np.nonzero(inside)[0]
-    order = pts[np.argsort(key[pts], kind="stable")]
-    skey = key[order]
-    starts = np.nonzero(np.r_[True, skey[1:] != skey[:-1]])[0] if len(order) else np.array([], dtype=np.int64)
-    ends = np.r_[starts[1:], len(order)] if len(order) else starts
-    dev = pc_in.device
-    indices, ijk = [], []
-    for s, e in zip(starts, ends):
-        kk = int(skey[s])
-        indices.append(torch.from_numpy(order[s:e].copy()).to(dev))
-        ijk.append((kk // (m * m), (kk // m) % m, kk % m))
+    key = (bx * m + by) * m + bz
+    pts = torch.nonzero(inside).flatten()
+    if pts.numel() == 0:
+        return [], []
+    skey, perm = torch.sort(key[pts], stable=True)
+    order = pts[perm]
+    ukeys, counts = torch.unique_consecutive(skey, return_counts=True)
+    indices = list(torch.split(order, counts.tolist()))
+    ijk = [(kk // (m * m), (kk // m) % m, kk % m) for kk in ukeys.tolist()]
     return indices, ijk
 
 
@@ -220,22 +244,56 @@ def pca_eigen_values(x: torch.Tensor):
     return e[0:1], v[:, 0]
 
 
+def _patch_covariances(pc: torch.Tensor, patches: List[torch.Tensor]):
+    """(pid[M], idx[M], mean[P,3], cov[P,3,3]) of the xyz of every listed patch, by two segmented sums."""
+    dev = pc.device
+    P = len(patches)
+    sizes = torch.tensor([int(p.shape[0]) for p in patches], device=dev)
+    idx = torch.cat([p.to(dev) for p in patches]) if P else torch.zeros(0, dtype=torch.long, device=dev)
+    pid = torch.repeat_interleave(torch.arange(P, device=dev), sizes)
+    xyz = pc[idx, :3]
+    cnt = sizes.to(xyz.dtype).clamp(min=1)[:, None]
+    mean = torch.zeros((P, 3), dtype=xyz.dtype, device=dev).index_add_(0, pid, xyz) / cnt
+    rel = xyz - mean[pid]
+    outer = (rel[:, :, None] * rel[:, None, :]).reshape(-1, 9)
+    cov = (torch.zeros((P, 9), dtype=xyz.dtype, device=dev).index_add_(0, pid, outer) / cnt).reshape(P, 3, 3)
+    return pid, idx, mean, cov
+
+
 def fix_n_filter(input_pc: torch.Tensor, patch_indices: List[torch.Tensor], threshold: float):
     """Keep patches whose flatness ratio e0 / (e1 + e2/2) exceeds threshold as (i, idx) pairs; the
     others get their normals aligned with their own PCA normal in place
-    (inference_utils.py:52-71 - pure torch, on the callers' path)."""
-    kept = []
-    for i, patch in enumerate(patch_indices):
-        x = input_pc[patch]
-        rel = x[:, :3] - x.mean(dim=0)[None, :3]
-        cov = (rel.transpose(0, 1) @ rel) / x.shape[0]
-        e, v = torch.linalg.eigh(cov)
-        if (e[0] / (e[1] + e[2] / 2)).item() > threshold:
-            kept.append((i, patch))
-        else:
-            s = ((input_pc[patch, 3:] * v[:, 0][None, :]).sum(dim=-1) > 0).to(input_pc.dtype) * 2 - 1
-            input_pc[patch, 3:] = input_pc[patch, 3:] * s[:, None]
+    (inference_utils.py:52-71 - pure torch, on the callers' path).  All covariances come from two
+    segmented sums and one batched eigh instead of one eigh per patch."""
+    if len(patch_indices) == 0:
+        return []
+    pid, idx, _, cov = _patch_covariances(input_pc, patch_indices)
+    e, v = torch.linalg.eigh(cov.cpu())
+    keep = (e[:, 0] / (e[:, 1] + e[:, 2] / 2)) > threshold
+    kept = [(i, patch) for i, patch in enumerate(patch_indices) if bool(keep[i])]
+    drop = ~keep.to(input_pc.device)
+    if bool(drop.any()):
+        sel = drop[pid]
+        rows, normal = idx[sel], v[:, :, 0].to(input_pc.device, input_pc.dtype)[pid[sel]]
+        s = ((input_pc[rows, 3:] * normal).sum(dim=-1) > 0).to(input_pc.dtype) * 2 - 1
+        input_pc[rows, 3:] = input_pc[rows, 3:] * s[:, None]
     return kept
+
+
+def orient_center_patches(input_pc: torch.Tensor, patches: List[torch.Tensor]) -> None:
+    """`for p in patches: input_pc[p] = orient_center(input_pc[p])` (orient_pointcloud.py:36-38) for disjoint
+    patches in one pass: flip the normals that point towards their patch's centroid."""
+    if len(patches) == 0:
+        return
+    allidx = torch.cat([p.to(input_pc.device) for p in patches])
+    if torch.bincount(allidx, minlength=input_pc.shape[0]).max() > 1:      # overlapping lists: literal loop
+        for p in patches:
+            input_pc[p] = orient_center(input_pc[p])
+        return
+    pid, idx, mean, _ = _patch_covariances(input_pc, patches)
+    inward = ((input_pc[idx, :3] - mean[pid]) * input_pc[idx, 3:]).sum(dim=-1) < 0
+    rows = idx[inward]
+    input_pc[rows, 3:] = -input_pc[rows, 3:]
 
 
 def estimate_normals(pc: torch.Tensor, max_nn: int = 30) -> torch.Tensor:
