@@ -33,6 +33,11 @@ SIGNATURES = {
                                             ctypes.c_float, _c_p, _c_p]),
     "dnp_interactions_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p]),
     "dnp_combine_fields_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, ctypes.c_int, _c_p]),
+    "dnp_xie_pairs_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, ctypes.c_float, ctypes.c_int,
+                                         _c_p, _c_p]),
+    "dnp_xie_pairs_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, ctypes.c_double, ctypes.c_int,
+                                         _c_p, _c_p]),
+    "dnp_xie_order_f32": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p]),
     "dnp_point_greedy_workspace_bytes": (_c_sz, [_c_i64]),
     "dnp_point_greedy_max_points": (ctypes.c_int, []),
     "dnp_point_greedy_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_i64, ctypes.c_float, ctypes.c_int, _c_p, _c_p,

@@ -1,0 +1,150 @@
+// dnp_xie.hip - the fork's "xie" pair functions:
+//   xie_field / xie_intersaction  (field_utils.py:431-469, :509-519)  -> dnp_xie_pairs_f32/_f64
+//   xie_propagation_points_in_order (field_utils.py:569-605)           -> dnp_xie_order_f32
+//
+// xie_pairs: the per-pair "reflected normal"  ref[t][s] = (n_s - C (n_s.r^) r^) / |r|^3,  r = x_s - x_t,
+// not divided when |r| == 0 (so a coincident pair yields n_s itself), and its projection on the target
+// normal M[t][s] = ref[t][s] . n_t with NaN/Inf -> 0.  The OUTPUT is the whole T x S matrix, so the kernel is
+// bound by HBM writes (4 or 12 bytes per pair against ~40 flops): lanes run along the source index so that
+// every store instruction writes 256 contiguous bytes of a row, targets are staged through LDS and broadcast.
+// Being write-bound, the arithmetic mirrors the reference's IEEE op order (sqrt, divisions, no fma
+// contraction) instead of the rsq/rcp chain of pair_kernel.h: the ordered propagation takes sign decisions on
+// row sums of this matrix.
+//
+// xie_order: for each of R visiting orders, N sequential steps  inter[idx] = sum_j M[idx][j] * w[j];
+// w[idx] = inter[idx] < 0 ? -1 : +1  (w starts at 0, so only visited points contribute).  One persistent
+// workgroup per order: per step one coalesced read of a matrix row, an fp64 tree reduction and two barriers.
+#include "dnp_common.h"
+
+#pragma clang fp contract(off)
+
+namespace dnp {
+
+constexpr int kXieBlock = 256;
+constexpr int kXieTargets = 64;   // targets staged per workgroup
+
+template <typename F>
+struct XieArgs {
+    const F* src; int64_t S; int64_t ld_src;
+    const F* tgt; int64_t T; int64_t ld_tgt;
+    F C;
+    int vector_out;
+    F* out;
+};
+
+template <typename F>
+__global__ __launch_bounds__(kXieBlock) void xie_pairs_kernel(const XieArgs<F> a) {
+    __shared__ F tl[kXieTargets][6];
+    const int tid = threadIdx.x;
+    const int64_t s = (int64_t)blockIdx.x * kXieBlock + tid;
+    const int64_t t0 = (int64_t)blockIdx.y * kXieTargets;
+    const int nt = (int)((a.T - t0) < kXieTargets ? (a.T - t0) : kXieTargets);
+    for (int i = tid; i < nt * 6; i += kXieBlock) {
+        const int r = i / 6, c = i - r * 6;
+        tl[r][c] = a.tgt[(t0 + r) * a.ld_tgt + c];
+    }
+    __syncthreads();
+    if (s >= a.S) return;
+    const F* ps = a.src + s * a.ld_src;
+    const F sx = ps[0], sy = ps[1], sz = ps[2], nx = ps[3], ny = ps[4], nz = ps[5];
+    for (int r = 0; r < nt; ++r) {
+        const F rx = sx - tl[r][0], ry = sy - tl[r][1], rz = sz - tl[r][2];      // R = source - target
+        const F nrm = __builtin_sqrt(rx * rx + ry * ry + rz * rz);
+        F fx, fy, fz;
+        if (nrm == F(0)) {
+            fx = nx; fy = ny; fz = nz;                    // R_unit = 0: n_s - C*0 ; not divided by |R|^3
+        } else {
+            const F ux = rx / nrm, uy = ry / nrm, uz = rz / nrm;
+            const F d = a.C * (nx * ux + ny * uy + nz * uz);
+            const F n3 = nrm * nrm * nrm;
+            fx = (nx - d * ux) / n3; fy = (ny - d * uy) / n3; fz = (nz - d * uz) / n3;
+        }
+        const int64_t o = (t0 + r) * a.S + s;
+        if (a.vector_out) {
+            a.out[o * 3 + 0] = fx; a.out[o * 3 + 1] = fy; a.out[o * 3 + 2] = fz;
+        } else {
+            F v = fx * tl[r][3] + fy * tl[r][4] + fz * tl[r][5];
+            if (!__builtin_isfinite(v)) v = F(0);           // intersaction[isnan / isinf] = 0
+            a.out[o] = v;
+        }
+    }
+}
+
+constexpr int kOrderThreads = 1024;
+
+__global__ __launch_bounds__(kOrderThreads) void xie_order_kernel(const float* __restrict__ M, int64_t N,
+                                                                 const int64_t* __restrict__ order,
+                                                                 float* __restrict__ weights,
+                                                                 float* __restrict__ inter) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t* ord = order + (int64_t)blockIdx.x * N;
+    float* w = weights + (int64_t)blockIdx.x * N;
+    float* out = inter + (int64_t)blockIdx.x * N;
+    __shared__ double part[kOrderThreads / 64];
+    for (int64_t j = tid; j < N; j += kOrderThreads) { w[j] = 0.f; out[j] = 0.f; }
+    __syncthreads();
+    for (int64_t i = 0; i < N; ++i) {
+        const int64_t idx = ord[i];
+        const float* row = M + idx * N;
+        double s = 0.0;
+        for (int64_t j = tid; j < N; j += kOrderThreads) s += (double)(row[j] * w[j]);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) part[wave] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int k = 0; k < kOrderThreads / 64; ++k) tot += part[k];
+            const float v = (float)tot;
+            out[idx] = v;
+            w[idx] = (v < 0.f) ? -1.f : 1.f;
+        }
+        __syncthreads();   // w[idx] is visible to the whole workgroup before the next row is weighted
+    }
+}
+
+template <typename F>
+static int run_xie_pairs(const F* src, int64_t S, int64_t ld_src, const F* tgt, int64_t T, int64_t ld_tgt, F C,
+                         int vector_out, F* out, hipStream_t stream) {
+    clear_error();
+    DNP_REQUIRE(S >= 0 && T >= 0, "negative size");
+    if (S == 0 || T == 0) return DNP_OK;
+    DNP_REQUIRE(src && tgt && out, "NULL pointer");
+    DNP_REQUIRE(ld_src >= 6 && ld_tgt >= 6, "xie pairs need 6-column sources and targets");
+    const int64_t gy = ceil_div(T, (int64_t)kXieTargets);
+    DNP_REQUIRE(gy <= 65535, "T=%lld exceeds %d targets per launch", (long long)T, 65535 * kXieTargets);
+    XieArgs<F> a{src, S, ld_src, tgt, T, ld_tgt, C, vector_out, out};
+    hipLaunchKernelGGL((xie_pairs_kernel<F>), dim3((unsigned)ceil_div(S, (int64_t)kXieBlock), (unsigned)gy),
+                       dim3(kXieBlock), 0, stream, a);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+}  // namespace dnp
+
+using namespace dnp;
+
+extern "C" {
+
+int dnp_xie_pairs_f32(const float* src, int64_t S, int64_t ld_src, const float* tgt, int64_t T, int64_t ld_tgt,
+                      float C, int vector_out, float* out, void* stream) {
+    return run_xie_pairs<float>(src, S, ld_src, tgt, T, ld_tgt, C, vector_out, out, (hipStream_t)stream);
+}
+
+int dnp_xie_pairs_f64(const double* src, int64_t S, int64_t ld_src, const double* tgt, int64_t T, int64_t ld_tgt,
+                      double C, int vector_out, double* out, void* stream) {
+    return run_xie_pairs<double>(src, S, ld_src, tgt, T, ld_tgt, C, vector_out, out, (hipStream_t)stream);
+}
+
+int dnp_xie_order_f32(const float* M, int64_t N, const int64_t* order, int64_t R, float* weights, float* inter,
+                      void* stream) {
+    clear_error();
+    DNP_REQUIRE(N >= 0 && R >= 0, "negative size");
+    if (N == 0 || R == 0) return DNP_OK;
+    DNP_REQUIRE(M && order && weights && inter, "NULL pointer");
+    hipLaunchKernelGGL(xie_order_kernel, dim3((unsigned)R), dim3(kOrderThreads), 0, (hipStream_t)stream, M, N, order,
+                       weights, inter);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+}  // extern "C"

@@ -27,7 +27,8 @@ __all__ = [
     "field_edge_calculator_bool", "field_edge_calculator_count", "self_interaction",
     "self_interaction_all", "random_self_interaction", "reference_field",
     "strongest_field_propagation_reps", "strongest_field_propagation",
-    "strongest_field_propagation_points", "torch", "np", "util",
+    "strongest_field_propagation_points", "xie_field", "xie_intersaction", "xie_distance",
+    "xie_propagation_points_in_order", "torch", "np", "util",
 ]
 
 # "auto": batched (all per-patch fields in one launch, greedy loop as P x P host arithmetic) when the
@@ -669,3 +670,95 @@ def _points_stepwise(work, diffuse, start):
         s = ((E * work[:, 3:]).sum(dim=-1) > 0).float() * 2 - 1
         work[:, 3:] = work[:, 3:] * s[:, None]
     return order
+
+
+# ---------------------------------------------------------------------------------------------------
+# the fork's "xie" pair functions (SURVEY section 8f-3)
+# ---------------------------------------------------------------------------------------------------
+def _xie_pairs(source, target, C, vector_out):
+    lib = _lib.require_device()
+    if source.dim() != 2 or source.shape[1] < 6 or target.dim() != 2 or target.shape[1] < 6:
+        raise ValueError("xie pair functions need [S,6] sources and [T,6] targets")
+    in_dev, in_dtype = target.device, torch.result_type(source, target)
+    dev = source.device if source.is_cuda else (target.device if target.is_cuda else _compute_device())
+    wd = _work_dtype(source, target)
+    src = _stage(source.detach(), dev, wd)
+    tgt = _stage(target.detach(), dev, wd)
+    S, T = src.shape[0], tgt.shape[0]
+    out = torch.empty((T, S, 3) if vector_out else (T, S), dtype=wd, device=dev)
+    if S and T:
+        fn = lib.dnp_xie_pairs_f64 if wd == torch.float64 else lib.dnp_xie_pairs_f32
+        with _on_device(dev):
+            rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(tgt), T, _ld(tgt), float(C), int(vector_out), _lib.ptr(out),
+                    _lib.current_stream())
+        _lib.check(rc)
+    return out.to(device=in_dev, dtype=in_dtype) if (out.device != in_dev or out.dtype != in_dtype) else out
+
+
+def _xie_knn_mask(source, target, k):
+    """[T,S] 0/1 mask: 1 where target t is among the k nearest targets of source s (the reference builds a
+    scipy KDTree on the targets and queries it with the sources, field_utils.py:451-460); brute force on the
+    tensors' device, distances in fp64."""
+    k = min(int(target.shape[0]), int(k))
+    sx, tx = source[:, :3].double(), target[:, :3].double()
+    mask = torch.zeros((target.shape[0], source.shape[0]), dtype=torch.float64, device=source.device)
+    step = max(1, (1 << 24) // max(int(target.shape[0]), 1))
+    for s0 in range(0, source.shape[0], step):
+        d2 = ((sx[s0:s0 + step, None, :] - tx[None, :, :]) ** 2).sum(dim=-1)          # [s, T]
+        nn = d2.topk(k, dim=1, largest=False).indices                                # [s, k]
+        cols = torch.arange(s0, s0 + nn.shape[0], device=source.device)[:, None].expand_as(nn)
+        mask[nn.reshape(-1), cols.reshape(-1)] = 1.0
+    return mask
+
+
+def xie_field(source: torch.Tensor, target: torch.Tensor, eps, max_pts=5000, knn_mask=-1, C=3):
+    """Reflected-normal pair field [T,S,3] (field_utils.py:431-469): (n_s - C (n_s.r^) r^)/|r|^3 with
+    r = x_s - x_t, left undivided for coincident pairs; optionally masked to the knn_mask nearest targets of
+    each source.  `eps` and `max_pts` are accepted and unused (the reference ignores eps; its recursion above
+    max_pts**2 pairs only bounds temporaries - and drops C / knn_mask on the way, which this does not)."""
+    with torch.no_grad():
+        out = _xie_pairs(source, target, C, True)
+        if knn_mask > 0:
+            out = out * _xie_knn_mask(source, target, knn_mask).to(out.device)[:, :, None]
+        return out
+
+
+def xie_intersaction(source: torch.Tensor, target: torch.Tensor, eps, knn_mask, C):
+    """[T,S] interaction matrix xie_field . n_t with NaN/Inf zeroed (field_utils.py:509-519)."""
+    with torch.no_grad():
+        if knn_mask > 0:
+            out = (xie_field(source, target, eps, knn_mask=knn_mask, C=C) * target[:, None, 3:]).sum(dim=-1)
+            out[out.isnan()] = 0
+            out[out.isinf()] = 0
+            return out
+        return _xie_pairs(source, target, C, False)
+
+
+def xie_distance(source: torch.Tensor, target: torch.Tensor, eps):
+    """sum_s |n_s * (x_s - x_t)| per target (field_utils.py:522-526); O(T*S*3) torch temporaries as there."""
+    R = source[None, :, :3] - target[:, None, :3]
+    return (source[None, :, 3:] * R).norm(dim=-1).sum(dim=-1)
+
+
+def xie_propagation_points_in_order(pts: torch.Tensor, eps, order, diffuse=False, verbose=False, points_weight=None,
+                                    knn_mask=-1, C=3):
+    """Ordered sign propagation (field_utils.py:569-605): for each of the T visiting orders in `order[T,N]`,
+    visit the points in that order, give every point the sign of the summed interaction with the points
+    visited before it, and return the [T,N] bool tensor `interactions < 0` (True = flipped).  `points_weight`
+    is accepted and has no effect, as in the reference (it multiplies by a tensor of ones)."""
+    lib = _lib.require_device()
+    with torch.no_grad():
+        dev = pts.device if pts.is_cuda else _compute_device()
+        work = pts.detach().to(device=dev, dtype=torch.float32).contiguous()
+        order_t = torch.as_tensor(np.asarray(order)).to(device=dev, dtype=torch.int64).contiguous()
+        T, N = order_t.shape
+        M = xie_intersaction(work, work, eps, knn_mask, C).to(torch.float32).contiguous()     # [N, N]
+        weights = torch.empty((T, N), dtype=torch.float32, device=dev)
+        inter = torch.empty((T, N), dtype=torch.float32, device=dev)
+        with _on_device(dev):
+            rc = lib.dnp_xie_order_f32(_lib.ptr(M), N, _lib.ptr(order_t), T, _lib.ptr(weights), _lib.ptr(inter),
+                                       _lib.current_stream())
+        _lib.check(rc)
+        if diffuse:
+            inter = weights @ M.transpose(0, 1)            # interactions[t][i] = sum_j M[i][j] * w[t][j]
+        return (inter < 0).to(pts.device)

@@ -153,6 +153,26 @@ int dnp_point_greedy_f32(float* pts, int64_t N, int64_t ld_pts, int64_t start, f
                          int diffuse, int64_t* order_out, float* E_out,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- the fork's "xie" pair functions -----------------------------------------
+ *
+ * dnp_xie_pairs: per-pair reflected normal  ref[t][s] = (n_s - C (n_s . r^) r^) / |r|^3,  r = x_s - x_t,
+ * left undivided when |r| == 0  (field_utils.xie_field, field_utils.py:431-469; its eps argument is unused
+ * there).  vector_out != 0: out is [T, S, 3] = ref;  vector_out == 0: out is [T, S] = ref . n_t with NaN/Inf
+ * zeroed (field_utils.xie_intersaction, field_utils.py:509-519).  Sources and targets are [*, >=6] rows.
+ *
+ * dnp_xie_order: the ordered propagation loop of field_utils.xie_propagation_points_in_order
+ * (field_utils.py:590-595) for R visiting orders over an N x N interaction matrix M (row = receiving point):
+ *   for i in 0..N-1:  idx = order[r][i];  inter[r][idx] = sum_j M[idx][j] * w[r][j];
+ *                     w[r][idx] = inter[r][idx] < 0 ? -1 : +1            (w starts at 0)
+ * weights / inter are [R, N] float outputs.
+ */
+int dnp_xie_pairs_f32(const float* src, int64_t S, int64_t ld_src, const float* tgt, int64_t T, int64_t ld_tgt,
+                      float C, int vector_out, float* out, void* stream);
+int dnp_xie_pairs_f64(const double* src, int64_t S, int64_t ld_src, const double* tgt, int64_t T, int64_t ld_tgt,
+                      double C, int vector_out, double* out, void* stream);
+int dnp_xie_order_f32(const float* M, int64_t N, const int64_t* order, int64_t R, float* weights, float* inter,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -249,3 +249,58 @@ def strongest_field_propagation_points(pts, diffuse=False, starting_point=0):
         s = ((E * pts[:, 3:]).sum(dim=-1) > 0).to(pts.dtype) * 2 - 1
         pts[:, 3:] = pts[:, 3:] * s[:, None]
     return pts, np.array(order)
+
+
+# ---- the fork's "xie" pair functions ----------------------------------------------------------------
+def xie_field(source, target, C=3):
+    """field_utils.py:431-469 without the kNN mask (eps is unused there): [T,S,3]."""
+    sep = source[None, :, :3] - target[:, None, :3]
+    dist = sep.norm(dim=-1)
+    apart = dist != 0
+    unit = torch.where(apart[:, :, None], sep / torch.where(apart, dist, torch.ones_like(dist))[:, :, None], sep)
+    n = source[None, :, 3:6]
+    refl = n - C * (n * unit).sum(dim=-1)[:, :, None] * unit
+    return torch.where(apart[:, :, None], refl / torch.where(apart, dist, torch.ones_like(dist))[:, :, None] ** 3, refl)
+
+
+def xie_knn_mask(source, target, k):
+    """field_utils.py:451-460: 1 where target t is among the k nearest targets (scipy KDTree) of source s."""
+    from scipy.spatial import KDTree
+    k = min(target.shape[0], k)
+    _, idx = KDTree(target[:, :3].numpy()).query(source[:, :3].numpy(), k=k)
+    idx = np.asarray(idx).reshape(source.shape[0], -1)
+    mask = torch.zeros(target.shape[0], source.shape[0], dtype=torch.float64)
+    for s in range(source.shape[0]):
+        mask[idx[s], s] = 1.0
+    return mask
+
+
+def xie_intersaction(source, target, knn_mask=-1, C=3):
+    """field_utils.py:509-519."""
+    f = xie_field(source, target, C)
+    if knn_mask > 0:
+        f = f * xie_knn_mask(source, target, knn_mask)[:, :, None]
+    m = (f * target[:, None, 3:6]).sum(dim=-1)
+    return torch.where(m.isnan() | m.isinf(), torch.zeros_like(m), m)
+
+
+def xie_distance(source, target):
+    """field_utils.py:522-526."""
+    return (source[None, :, 3:] * (source[None, :, :3] - target[:, None, :3])).norm(dim=-1).sum(dim=-1)
+
+
+def xie_propagation_points_in_order(pts, order, diffuse=False, knn_mask=-1, C=3):
+    """field_utils.py:569-605: [T,N] bool, True where the summed interaction is negative."""
+    order = torch.as_tensor(np.asarray(order)).long()
+    T, N = order.shape
+    M = xie_intersaction(pts, pts, knn_mask, C).to(pts.dtype)
+    w = torch.zeros(T, N, dtype=pts.dtype)
+    inter = torch.zeros(T, N, dtype=pts.dtype)
+    rows = torch.arange(T)
+    for i in range(N):
+        idx = order[:, i]
+        inter[rows, idx] = (M[idx] * w).sum(dim=-1)
+        w[rows, idx] = torch.where(inter[rows, idx] < 0, -1.0, 1.0).to(pts.dtype)
+    if diffuse:
+        inter = (M[None, :, :] * w[:, None, :]).sum(dim=-1)
+    return inter < 0

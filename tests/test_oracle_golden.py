@@ -205,3 +205,30 @@ def test_G8_point_propagation(tag):
     assert np.array_equal(order, g[f"order_{tag}"])
     sign = ((out[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy()
     assert np.array_equal(sign, g[f"sign_{tag}"])
+
+
+# ---- the fork's "xie" pair functions (GX) --------------------------------------------------------------
+def test_GX_xie_pair_functions():
+    g = load_golden("GX_xie")
+    src, tgt = t(g["src"]), t(g["tgt"])
+    for C in (3, 2):
+        f = O.xie_field(src, tgt, C=C).numpy()
+        scale = np.abs(g[f"field_C{C}"]).max()
+        assert f.shape == (40, 50, 3) and np.abs(f - g[f"field_C{C}"]).max() / scale < 1e-6
+        m = O.xie_intersaction(src, tgt, C=C).numpy()
+        assert np.abs(m - g[f"inter_C{C}"]).max() / np.abs(g[f"inter_C{C}"]).max() < 1e-6
+    # coincident pairs are left undivided: ref = n_s
+    assert np.allclose(g["field_C3"][0, 10], g["src"][10, 3:]) and np.allclose(g["field_C3"][4, 14], g["src"][14, 3:])
+    mk = O.xie_intersaction(src, tgt, knn_mask=5, C=3).numpy()
+    assert np.array_equal(mk != 0, g["inter_knn5"] != 0)
+    assert np.abs(mk - g["inter_knn5"]).max() / np.abs(g["inter_knn5"]).max() < 1e-6
+    assert np.allclose(O.xie_intersaction(src.double(), tgt.double()).numpy(), g["inter64"], rtol=1e-12, atol=1e-12)
+    assert np.allclose(O.xie_distance(src, tgt).numpy(), g["distance"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag,diffuse,knn", [("n_k0", False, -1), ("d_k0", True, -1), ("n_k20", False, 20)])
+def test_GX_ordered_propagation(tag, diffuse, knn):
+    g = load_golden("GX_xie")
+    res = O.xie_propagation_points_in_order(t(g["pc"]), g["orders"], diffuse=diffuse, knn_mask=knn).numpy()
+    assert res.shape == (3, 1000)
+    assert (res != g[f"flip_{tag}"]).sum() <= 2        # row sums within fp32 noise of zero may differ

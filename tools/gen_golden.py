@@ -403,6 +403,36 @@ def gh(fu, util):
     save("GH_xyz_parse", parsed=util.xyz2tensor(txt), parsed_noappend=util.xyz2tensor("1 2 3\n4 5 6", append_normals=False))
 
 
+def gx(fu, util):
+    """The fork's 'xie' pair functions that are pure torch given an order:
+    xie_field / xie_intersaction / xie_distance (field_utils.py:431-519) and
+    xie_propagation_points_in_order (field_utils.py:569-605)."""
+    g = torch.Generator().manual_seed(31)
+    src = torch.randn(50, 6, generator=g)
+    tgt = torch.randn(40, 6, generator=g)
+    tgt[:5, :3] = src[10:15, :3]                      # coincident pairs: not divided by |R|^3
+    out = dict(src=src, tgt=tgt)
+    for C in (3, 2):
+        out[f"field_C{C}"] = fu.xie_field(src, tgt, eps=0.1, C=C)
+        out[f"inter_C{C}"] = fu.xie_intersaction(src, tgt, eps=0.1, knn_mask=-1, C=C)
+    out["inter_knn5"] = fu.xie_intersaction(src, tgt, eps=0.1, knn_mask=5, C=3)
+    out["inter64"] = fu.xie_intersaction(src.double(), tgt.double(), eps=0.1, knn_mask=-1, C=3)
+    out["distance"] = fu.xie_distance(src, tgt, eps=0.1)
+    # ordered propagation on the 1000-point ok.xyz subsample, three visiting orders
+    pc = torch.from_numpy(np.load(os.path.join(OUT, "G8_point_propagation.npz"))["pc_sub1000"])
+    orders = np.stack([np.arange(1000), torch.randperm(1000, generator=g).numpy(), np.arange(1000)[::-1].copy()])
+    out["pc"] = pc
+    out["orders"] = orders
+    for diffuse in (False, True):
+        for knn in (-1, 20):
+            t0 = time.time()
+            res = fu.xie_propagation_points_in_order(pc.clone(), 0.1, orders, diffuse=diffuse, knn_mask=knn, C=3)
+            out[f"flip_{'d' if diffuse else 'n'}_k{knn if knn > 0 else 0}"] = res
+            print(f"  GX in_order diffuse={diffuse} knn={knn}: {time.time() - t0:.1f}s, flipped {int(res.sum())}")
+    out["inter_pc"] = fu.xie_intersaction(pc, pc, eps=0.1, knn_mask=-1, C=3)[:64]
+    save("GX_xie", **out)
+
+
 def make_inference_shim():
     """inference_utils.py imports models/ (torch_geometric, absent offline) at module level.
     Only its pure-torch fix_n_filter is on the path; load that one function's source object by
@@ -418,7 +448,7 @@ def make_inference_shim():
     spec.loader.exec_module(mod)
 
 
-ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh)
+ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
