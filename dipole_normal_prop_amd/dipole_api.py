@@ -11,6 +11,24 @@ def orient_large(opts):
     return _run_large(opts)
 
 
+def simple_estimate(xyz_data, config):
+    """The request handler behind the reference's socket servers (socket_server.py:18-27): numpy xyz in
+    (float64 on the wire) -> PCA normals -> unit-box transform -> per-point dipole propagation -> global flip
+    by the mean potential -> numpy [N,6] out in the input's frame and dtype.  The TCP framing itself
+    (JSON header + raw float64, socket_server_para.py:142-195) is outside this package.  The propagation runs
+    in fp32 on the GPU whatever the input dtype (the reference would run it in fp64 for a float64 cloud)."""
+    import torch
+    from . import field_utils, util
+    dev = torch.device("cuda", torch.cuda.current_device())
+    input_pc = util.npxyz2tensor(xyz_data).to(dev)
+    input_pc = util.estimate_normals(input_pc, max_nn=30)
+    input_pc, transform = util.Transform.trans(input_pc)
+    field_utils.strongest_field_propagation_points(input_pc, diffuse=config["diffuse"], starting_point=0)
+    if field_utils.measure_mean_potential(input_pc) < 0:
+        input_pc[:, 3:] *= -1
+    return transform.inverse(input_pc).cpu().numpy()
+
+
 def get_parser():
     p = options.get_parser('dipole api')
     p.set_defaults(number_parts=10, minimum_points_per_patch=100, iters=5, diffuse=True, weighted_prop=True)

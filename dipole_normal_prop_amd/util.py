@@ -99,6 +99,15 @@ def xyz2tensor(txt: str, append_normals: bool = True) -> torch.Tensor:
     return torch.tensor(rows, dtype=torch.float32)
 
 
+def npxyz2tensor(np_pc, append_normals: bool = True) -> torch.Tensor:
+    """numpy cloud -> tensor of the same dtype (the socket path feeds float64), zero normals appended to a
+    3-column cloud (util.py:71-77)."""
+    np_pc = np.asarray(np_pc)
+    if np_pc.shape[1] == 3 and append_normals:
+        np_pc = np.concatenate([np_pc, np.zeros((np_pc.shape[0], 3), dtype=np_pc.dtype)], axis=1)
+    return torch.tensor(np_pc)
+
+
 def load_xyz(path, append_normals: bool = True) -> torch.Tensor:
     with open(path, "r") as fh:
         return xyz2tensor(fh.read(), append_normals=append_normals)

@@ -145,6 +145,18 @@ def test_reference_orientation_both_forms(dev, tmp_path):
     assert util.load_xyz(tmp_path / "o6.xyz").shape == (10000, 6)
 
 
+def test_simple_estimate_request_handler(dev):
+    """socket_server.simple_estimate: float64 xyz in, [N,6] float64 out, consistently oriented normals."""
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(3000, 3, generator=gen, dtype=torch.float64)
+    x = (x / x.norm(dim=-1, keepdim=True) * 2.5 + 7.0).numpy()        # a sphere away from the origin
+    out = dipole_api.simple_estimate(x, {"diffuse": True})
+    assert out.shape == (3000, 6) and out.dtype == np.float64
+    assert np.abs(out[:, :3] - x).max() < 1e-5
+    radial = (out[:, :3] - 7.0) / 2.5
+    assert ((out[:, 3:] * radial).sum(-1) > 0).mean() == 1.0          # outward: positive mean potential
+
+
 def test_models_flag_is_rejected(tmp_path):
     o = options.get_parser().parse_args(["--pc", "x.xyz", "--export_dir", str(tmp_path), "--models", "a.pt"])
     with pytest.raises(SystemExit):
