@@ -2,7 +2,7 @@
 own parser (dipole_api.py:101-132; the reference hard-codes Windows paths as defaults, here --pc and
 --export_dir are required instead)."""
 from . import options
-from .orient_large import run as _run_large
+from .pipeline import orient_representatives as _run_large
 
 
 def orient_large(opts):
@@ -36,7 +36,4 @@ def get_parser():
 
 
 if __name__ == '__main__':
-    opts = get_parser().parse_args()
-    opts.export_dir.mkdir(exist_ok=True, parents=True)
-    options.export_options(opts)
-    orient_large(opts)
+    options.main(orient_large, get_parser())
