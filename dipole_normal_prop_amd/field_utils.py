@@ -474,24 +474,30 @@ def _sequential_patch_propagation(work, patches: List[torch.Tensor], start: int,
         if tgt_idx.numel():
             _pairs_into("field", work, src_idx, work, tgt_idx, eps, 15000, E, out_scatter=True, accumulate=True)
 
-    remaining = list(range(P))
-    remaining.remove(start)
+    # per-step interaction of every patch by ONE segmented sum over the concatenated index lists (works for
+    # overlapping lists too), instead of one gather per remaining patch
+    sizes = torch.tensor([int(p.shape[0]) for p in pidx], device=dev)
+    cat_idx = torch.cat(pidx) if P else torch.zeros(0, dtype=torch.int64, device=dev)
+    pending = torch.ones(P, dtype=torch.bool, device=dev)
+    pending[start] = False
     oriented[pidx[start]] = True
     # E[~mask] = field_grad(pts[start], pts[~start])
     tgt0 = all_rows[~oriented]
     if tgt0.numel():
         _pairs_into("field", work, pidx[start], work, tgt0, eps, 15000, E, out_scatter=True, accumulate=True)
     order, sigma, chosen = [start], np.ones(P), []
-    while remaining:
+    neg_inf = torch.full((P,), float("-inf"), dtype=torch.float64, device=dev)
+    for _ in range(P - 1):
         dots = (E * work[:, 3:]).sum(dim=-1)
-        inter = torch.stack([dots[pidx[k]].sum() for k in remaining])
-        m = int(inter.abs().argmax().item())
-        k = remaining.pop(m)
-        v = float(inter[m])
+        inter = torch.segment_reduce(dots[cat_idx].double(), "sum", lengths=sizes)   # deterministic, in patch order
+        # first maximum in patch order among the pending ones == argmax over the reference's `remaining` list
+        k = int(torch.where(pending, inter.abs(), neg_inf).argmax().item())
+        v = float(inter[k])
         chosen.append(v)
         if v < 0:
             work[pidx[k], 3:] *= -1
             sigma[k] = -1.0
+        pending[k] = False
         oriented[pidx[k]] = True
         order.append(k)
         add_field(k)
