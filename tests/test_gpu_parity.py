@@ -498,3 +498,77 @@ def test_sphere100k_256_patches_propagation_recovers_orientation(dev):
     assert sorted(tr["order"].tolist()) == list(range(256))
     s = tr["sigma"][~flip.numpy()]
     assert np.all(tr["sigma"][flip.numpy()] == -s[0]) and np.all(s == s[0])
+
+
+# ---- randomized shapes / strides / gathers (launch planning and indexing) --------------------------------
+def test_fuzz_shapes_strides_gathers_against_oracle(dev):
+    """Random S, T (including T >= 65 536, where the 4-targets-per-lane kernel is used, and sizes straddling tile
+    and chunk boundaries), wide row strides, row gathers on either operand, scattered accumulation and leaf
+    limits - every result against the fp64 C oracle on a row sample."""
+    lib = _lib.require_device()
+    rng = np.random.default_rng(2024)
+    cases = [(37, 70001), (1, 65536), (1030, 66000), (5, 131075)] + \
+            [(int(rng.integers(1, 3000)), int(rng.integers(1, 5000))) for _ in range(20)]
+    for case, (S, T) in enumerate(cases):
+        gen = torch.Generator().manual_seed(1000 + case)
+        ld_s, ld_t = int(rng.integers(6, 10)), int(rng.integers(3, 9))
+        nrow_s, nrow_t = S + int(rng.integers(0, 50)), T + int(rng.integers(0, 50))
+        src_all = torch.rand(nrow_s, ld_s, generator=gen) - 0.5
+        tgt_all = torch.rand(nrow_t, ld_t, generator=gen) - 0.5
+        use_si, use_ti = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        si = torch.randperm(nrow_s, generator=gen)[:S] if use_si else None
+        ti = torch.randperm(nrow_t, generator=gen)[:T] if use_ti else None
+        scatter = use_ti and bool(rng.integers(0, 2))
+        accumulate = bool(rng.integers(0, 2))
+        max_pts = int(rng.choice([0, 15000, 700]))
+        eps = float(rng.choice([1e-5, 1e-6, 1e-3]))
+        src_rows = src_all[si] if use_si else src_all[:S]
+        tgt_rows = tgt_all[ti] if use_ti else tgt_all[:T]
+        sample = np.unique(np.r_[0, T - 1, rng.integers(0, T, size=min(T, 48))])
+        ref = c_oracle.field_grad_f64(src_rows[:, :6].numpy(), tgt_rows[sample][:, :3].numpy(), eps=eps,
+                                      recursive=max_pts > 0, max_pts=max_pts if max_pts > 0 else 15000)
+        out_rows = nrow_t if scatter else T
+        out0 = torch.randn(out_rows, 3, generator=gen) * 10
+        d_src, d_tgt, d_out = src_all.to(dev), tgt_all.to(dev), out0.to(dev)
+        d_si = si.to(dev) if use_si else None
+        d_ti = ti.to(dev) if use_ti else None
+        nbytes = lib.dnp_field_grad_workspace_bytes(S, T, max_pts)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        rc = lib.dnp_field_grad_f32(_lib.ptr(d_src), S, ld_s, _lib.ptr(d_si), _lib.ptr(d_tgt), T, ld_t, _lib.ptr(d_ti),
+                                    eps, max_pts, _lib.ptr(d_out), 3, int(scatter), int(accumulate), _lib.ptr(ws), nbytes,
+                                    _lib.current_stream())
+        assert rc == 0, (case, lib.dnp_last_error())
+        torch.cuda.synchronize()
+        out = d_out.cpu()
+        rows_out = ti[sample] if scatter else torch.from_numpy(sample)
+        got = out[rows_out].double().numpy() - (out0[rows_out].double().numpy() if accumulate else 0.0)
+        err = np.linalg.norm(got - ref, axis=1)
+        mag = term_magnitude(src_rows[:, :6].numpy(), tgt_rows[sample][:, :3].numpy(), eps=eps)
+        slack = 1e-6 * np.abs(out0[rows_out].numpy()).max() if accumulate else 0.0      # fp32 rounding of out0 + E
+        assert np.all(err <= TOL * np.linalg.norm(ref, axis=1) + 16 * 2.0 ** -24 * mag + slack), \
+            f"case {case}: S={S} T={T} ld=({ld_s},{ld_t}) idx=({use_si},{use_ti}) scatter={scatter} acc={accumulate}"
+        if scatter:                                           # rows that are not targets stay untouched
+            mask = torch.ones(nrow_t, dtype=torch.bool)
+            mask[ti] = False
+            assert torch.equal(out[mask], out0[mask])
+
+
+# ---- a second cloud for the greedy drivers: hand.xyz (G13) --------------------------------------------------
+def test_G13_hand_point_and_patch_propagation(dev):
+    g = load_golden("G13_hand")
+    cloud = t(g["pc_scrambled"])
+    pts = cloud.clone().to(dev)
+    fu.strongest_field_propagation_points(pts, diffuse=True, starting_point=17)
+    order = fu.strongest_field_propagation_points.last_trace["order"].cpu().numpy()
+    assert np.array_equal(order, g["order_points"])                           # all 10 000 steps
+    assert np.array_equal(((pts.cpu()[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g["sign_points"])
+    pc_patch = t(g["pc_patchflip"])
+    allp = csr_to_list(g["patch_off"], g["patch_idx"])
+    work = pc_patch.clone().to(dev)
+    fu.strongest_field_propagation(work, [(i, p.to(dev)) for i, p in enumerate(allp)], [p.to(dev) for p in allp],
+                                   diffuse=True, start_patch=int(g["order_patch"][0]))
+    tr = fu.strongest_field_propagation.last_trace
+    assert np.array_equal(tr["order"], g["order_patch"])
+    assert np.array_equal((tr["sigma"] < 0)[tr["order"]], g["flipped_patch"])
+    assert np.allclose(tr["chosen"], g["chosen_patch"], rtol=2e-4)
+    assert np.array_equal(((work.cpu()[:, 3:] * pc_patch[:, 3:]).sum(-1) > 0).numpy(), g["sign_patch"])

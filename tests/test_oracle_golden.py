@@ -232,3 +232,13 @@ def test_GX_ordered_propagation(tag, diffuse, knn):
     res = O.xie_propagation_points_in_order(t(g["pc"]), g["orders"], diffuse=diffuse, knn_mask=knn).numpy()
     assert res.shape == (3, 1000)
     assert (res != g[f"flip_{tag}"]).sum() <= 2        # row sums within fp32 noise of zero may differ
+
+
+def test_G13_hand_patch_propagation():
+    g = load_golden("G13_hand")
+    cloud = t(g["pc_patchflip"])
+    allp = csr_to_list(g["patch_off"], g["patch_idx"])
+    out, trace = O.strongest_field_propagation(cloud, list(enumerate(allp)), allp, diffuse=True,
+                                               start_patch=int(g["order_patch"][0]))
+    assert np.array_equal(trace["order"], g["order_patch"]) and np.array_equal(trace["flipped"], g["flipped_patch"])
+    assert np.array_equal(((out[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g["sign_patch"])

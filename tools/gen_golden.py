@@ -433,6 +433,49 @@ def gx(fu, util):
     save("GX_xie", **out)
 
 
+def g13(fu, util):
+    """A second cloud for the greedy drivers: hand.xyz (10 000 points) - full per-point visit order, and the
+    patch driver at n_part 20 / min 50 (different partition than G6), both with scrambled signs."""
+    raw = load_cloud(util, "hand")
+    pc, _ = util.Transform.trans(raw)
+    cloud0, _ = scramble_signs(pc, 13)
+    out = dict(raw=raw, pc_scrambled=cloud0)
+    order = []
+    orig_fg = fu.field_grad
+
+    def rec_fg(sources, means, *a, **k):
+        order.append(sources.storage_offset() // 6)
+        return orig_fg(sources, means, *a, **k)
+
+    fu.field_grad = rec_fg
+    t0 = time.time()
+    try:
+        pts = fu.strongest_field_propagation_points(cloud0.clone(), diffuse=True, starting_point=17)
+    finally:
+        fu.field_grad = orig_fg
+    out["order_points"] = np.array(order)
+    out["sign_points"] = ((pts[:, 3:] * cloud0[:, 3:]).sum(-1) > 0)
+    print(f"  G13 per-point: {time.time() - t0:.1f}s")
+    allp = ref_patches(util, pc, 20, 50)
+    print(f"  hand patches: {len(allp)}")
+    g = torch.Generator().manual_seed(14)
+    pflip = torch.rand(len(allp), generator=g) < 0.5
+    pc_patch = pc.clone()
+    for k, idx in enumerate(allp):
+        if pflip[k]:
+            pc_patch[idx, 3:] *= -1
+    patches = list(enumerate(allp))
+    ptsp, calls, inter = _run_patch_driver(fu, util, "patch", pc_patch, patches, allp, True, None)
+    firsts = [(int(p[0]), pc_patch[int(p[0]), :3]) for p in allp]
+    mins = [(int(p.min()), pc_patch[int(p.min()), :3]) for p in allp]
+    order_p, flipped_p = _order_from_calls(calls, pc_patch, firsts, mins)
+    out.update(pc_patchflip=pc_patch, patch_off=np.cumsum([0] + [len(p) for p in allp]), patch_idx=torch.cat(allp),
+               order_patch=order_p, flipped_patch=flipped_p,
+               chosen_patch=np.array([float(t[t.abs().argmax()]) for t in inter]),
+               sign_patch=((ptsp[:, 3:] * pc_patch[:, 3:]).sum(-1) > 0))
+    save("G13_hand", **out)
+
+
 def make_inference_shim():
     """inference_utils.py imports models/ (torch_geometric, absent offline) at module level.
     Only its pure-torch fix_n_filter is on the path; load that one function's source object by
@@ -448,7 +491,7 @@ def make_inference_shim():
     spec.loader.exec_module(mod)
 
 
-ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx)
+ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
