@@ -4,8 +4,8 @@
 // Single-workgroup form (N <= 512*PPT): 512 threads = 8 waves = 2 per SIMD, so every lane may
 // hold up to 24 points (x, n, E: 9 floats each) in its 256-VGPR budget.  One step =
 //   (1) every lane scans its unvisited points for max |E.n|            (registers only)
-//   (2) wave argmax by DPP shuffles, 8 wave results through LDS, ONE barrier per step
-//       (slots double-buffered by step parity)
+//   (2) every lane folds (|E.n|, index, sign) into one 64-bit key and does ONE ds_max_u64 on a word in LDS,
+//       ONE barrier per step (three words in rotation)
 //   (3) every wave reads the winner's row with wave-uniform loads - pts[] is read-only during
 //       the loop: a point's normal flips at most once, when it is chosen, and is never read by
 //       anybody else afterwards, so the owner just remembers the flip and writes it at the end
@@ -30,18 +30,6 @@ namespace dnp {
 
 constexpr int kGreedyThreads = 512;
 
-struct Best {
-    float a;      // |interaction|
-    float v;      // signed interaction
-    int idx;      // point index (INT_MAX = none)
-};
-
-__device__ __forceinline__ Best better(const Best& p, const Best& q) {
-    // larger |v| wins; ties -> smaller index
-    const bool take_q = (q.a > p.a) || (q.a == p.a && q.idx < p.idx);
-    return take_q ? q : p;
-}
-
 __device__ __forceinline__ void add_dipole_field(float sx, float sy, float sz, float px, float py, float pz,
                                                  float x, float y, float z, float eps, float& ex, float& ey,
                                                  float& ez) {
@@ -65,15 +53,27 @@ __device__ __forceinline__ void add_dipole_field(float sx, float sy, float sz, f
     ex += fx; ey += fy; ez += fz;
 }
 
+// Candidate key: one 64-bit word whose unsigned order is the selection order of the greedy step -
+//   bits 63..32  |interaction| as its IEEE bit pattern (monotone for non-negative floats)
+//   bits 31..1   0x7fffffff - point index   (ties in |interaction| go to the smallest index, as torch.argmax)
+//   bit  0       1 when the interaction is negative
+// so a workgroup's winner is ONE ds_max_u64 per lane instead of a 6-step shuffle tree over three values.
+__device__ __forceinline__ unsigned long long candidate_key(float v, int idx) {
+    const unsigned absbits = __builtin_bit_cast(unsigned, __builtin_fabsf(v));
+    const unsigned low = ((0x7fffffffu - (unsigned)idx) << 1) | (v < 0.f ? 1u : 0u);
+    return ((unsigned long long)absbits << 32) | low;
+}
+constexpr unsigned long long kNoCandidate = 0ull;   // below every real key (index field of a real key is > 0)
+
 template <int PPT>
 __global__ __launch_bounds__(kGreedyThreads) void point_greedy_kernel(float* __restrict__ pts, int64_t N,
                                                                       int64_t ld, int start, float eps, int diffuse,
                                                                       int64_t* __restrict__ order_out,
                                                                       float* __restrict__ E_out) {
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    constexpr int kWaves = kGreedyThreads / 64;
-    __shared__ Best slots[2][kWaves];
+    __shared__ unsigned long long best_key[3];      // rotating, see the step loop
+    if (tid == 0) best_key[0] = best_key[1] = best_key[2] = kNoCandidate;
+    __syncthreads();
 
     float x[PPT], y[PPT], z[PPT], nx[PPT], ny[PPT], nz[PPT], ex[PPT], ey[PPT], ez[PPT];
     unsigned visited = 0, flipped = 0, valid = 0;
@@ -113,34 +113,27 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_kernel(float* __r
         }
         if (step + 1 == N) break;
 
-        // (1) local scan
-        Best b{-1.f, 0.f, 0x7fffffff};
+        // (1) local scan -> (2) one LDS atomic max of the packed candidate key per lane, ONE barrier per step
+        unsigned long long key = kNoCandidate;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             if (!((visited >> k) & 1u)) {
                 // an unvisited point has not been flipped: its normal is the input normal
                 const float v = ex[k] * nx[k] + ey[k] * ny[k] + ez[k] * nz[k];
-                const Best c{__builtin_fabsf(v), v, k * kGreedyThreads + tid};
-                b = better(b, c);
+                const unsigned long long c = candidate_key(v, k * kGreedyThreads + tid);
+                key = c > key ? c : key;
             }
         }
-        // (2) wave argmax, then across waves
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            Best o;
-            o.a = __shfl_xor(b.a, off, 64);
-            o.v = __shfl_xor(b.v, off, 64);
-            o.idx = __shfl_xor(b.idx, off, 64);
-            b = better(b, o);
-        }
-        const int par = (int)(step & 1);
-        if (lane == 0) slots[par][wave] = b;
+        // three words in rotation: word (step+1)%3 was last READ right after the barrier of step-2, i.e. before
+        // every thread's arrival at the barrier of step-1, so thread 0 may clear it now; it is next written
+        // after this step's barrier
+        const int par = (int)(step % 3);
+        if (tid == 0) best_key[(par + 1) % 3] = kNoCandidate;
+        if (key != kNoCandidate) atomicMax(&best_key[par], key);
         __syncthreads();
-        Best g = slots[par][0];
-#pragma unroll
-        for (int w = 1; w < kWaves; ++w) g = better(g, slots[par][w]);
-        cur = __builtin_amdgcn_readfirstlane(g.idx);   // wave-uniform: the row fetch becomes scalar loads
-        cur_sign = (g.v < 0.f) ? -1.f : 1.f;   // `if interaction[max] < 0: flip`
+        const unsigned long long gk = best_key[par];
+        cur = __builtin_amdgcn_readfirstlane((int)(0x7fffffffu - (unsigned)((gk & 0xffffffffull) >> 1)));
+        cur_sign = (gk & 1ull) ? -1.f : 1.f;                 // `if interaction[max] < 0: flip`
     }
 
     // epilogue: write flips, optional diffuse sign pass (field_utils.py:382-385), E_out
@@ -190,11 +183,11 @@ struct MultiArgs {
 template <int PPT>
 __global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(const MultiArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int kWaves = kGreedyThreads / 64;
     const int G = gridDim.x, g = blockIdx.x;
     const int64_t base = (int64_t)g * a.per_group;
-    __shared__ Best slots_l[kWaves];
-    __shared__ Best global_best;
+    __shared__ unsigned long long local_key[2];     // per step parity
+    __shared__ float win_row[8];                    // winner's (x, y, z, nx, ny, nz, signed interaction)
+    __shared__ int win_idx;
     __shared__ int abort_flag;
 
     float x[PPT], y[PPT], z[PPT], nx[PPT], ny[PPT], nz[PPT], ex[PPT], ey[PPT], ez[PPT];
@@ -211,16 +204,23 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(cons
         }
     }
     visited = ~valid;
-    if (tid == 0) abort_flag = 0;
+    if (tid == 0) {
+        abort_flag = 0;
+        local_key[0] = local_key[1] = kNoCandidate;
+        const float* p = a.pts + (int64_t)a.start * a.ld;
+        for (int c = 0; c < 6; ++c) win_row[c] = p[c];
+        win_row[6] = 1.f;                            // the start point is not flipped
+        win_idx = a.start;
+    }
     __syncthreads();
 
-    int cur = a.start;
-    float cur_sign = 1.f;
     for (int64_t step = 0; step < a.N; ++step) {
+        // the chosen point's row comes from LDS: wave 0 fetched it while it was polling (or the prologue did)
+        const int cur = win_idx;
+        const float cur_sign = (win_row[6] < 0.f) ? -1.f : 1.f;     // `if interaction[max] < 0: flip`
         {
-            const float* p = a.pts + (int64_t)cur * a.ld;
-            const float sx = p[0], sy = p[1], sz = p[2];
-            const float px = p[3] * cur_sign, py = p[4] * cur_sign, pz = p[5] * cur_sign;
+            const float sx = win_row[0], sy = win_row[1], sz = win_row[2];
+            const float px = win_row[3] * cur_sign, py = win_row[4] * cur_sign, pz = win_row[5] * cur_sign;
             const int64_t rel = (int64_t)cur - base;
             const bool mine = rel >= 0 && rel < a.per_group;
             const int ck = mine ? (int)(rel / kGreedyThreads) : -1, ct = mine ? (int)(rel - (int64_t)ck * kGreedyThreads) : -1;
@@ -238,40 +238,43 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(cons
         }
         if (step + 1 == a.N) break;
 
-        Best b{-1.f, 0.f, 0x7fffffff};
+        // local winner: one LDS atomic max per lane that has a candidate
+        unsigned long long key = kNoCandidate;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             if (!((visited >> k) & 1u)) {
                 const float v = ex[k] * nx[k] + ey[k] * ny[k] + ez[k] * nz[k];
-                const Best c{__builtin_fabsf(v), v, (int)(base + (int64_t)k * kGreedyThreads + tid)};
-                b = better(b, c);
+                const unsigned long long c = candidate_key(v, (int)(base + (int64_t)k * kGreedyThreads + tid));
+                key = c > key ? c : key;
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            Best o;
-            o.a = __shfl_xor(b.a, off, 64);
-            o.v = __shfl_xor(b.v, off, 64);
-            o.idx = __shfl_xor(b.idx, off, 64);
-            b = better(b, o);
-        }
-        if (lane == 0) slots_l[wave] = b;
-        __syncthreads();
+        const int par = (int)(step & 1);
+        if (key != kNoCandidate) atomicMax(&local_key[par], key);
+        __syncthreads();                              // (also orders this step's win_row reads before its rewrite)
         if (wave == 0) {
-            Best wg = slots_l[0];
-#pragma unroll
-            for (int w = 1; w < kWaves; ++w) wg = better(wg, slots_l[w]);
             const unsigned tag = (unsigned)(step & 0xfff);
-            unsigned long long* row = a.slots + (size_t)(step & 1) * kMaxGroups;
+            unsigned long long* row = a.slots + (size_t)par * kMaxGroups;
             if (lane == 0) {
-                // a workgroup with nothing left publishes index kIdxMask (never a real point: N < 2^20)
-                const unsigned idx = (wg.idx == 0x7fffffff) ? kIdxMask : (unsigned)wg.idx;
+                const unsigned long long lk = local_key[par];
+                local_key[par] = kNoCandidate;        // ready for step + 2 (step + 1 uses the other word)
+                // granule: the key's low word carries index and sign; its high word (|v| bits) keeps the top 20
+                // bits for |v| ... no: the granule must also carry the step tag, so it is re-packed:
+                //   { float signed_interaction ; tag << 20 | index }   (index kIdxMask = no candidate)
+                unsigned idx = kIdxMask;
+                float v = 0.f;
+                if (lk != kNoCandidate) {
+                    idx = 0x7fffffffu - (unsigned)((lk & 0xffffffffull) >> 1);
+                    v = __builtin_bit_cast(float, (unsigned)(lk >> 32));
+                    if (lk & 1ull) v = -v;
+                }
                 const unsigned long long gran = ((unsigned long long)((tag << kTagShift) | idx) << 32) |
-                                                (unsigned long long)__builtin_bit_cast(unsigned, wg.v);
+                                                (unsigned long long)__builtin_bit_cast(unsigned, v);
                 __hip_atomic_store(row + g, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // all-gather: lane l polls groups l, l+64, ...
-            Best best{-1.f, 0.f, 0x7fffffff};
+            // all-gather: lane l polls groups l, l+64, ...; as soon as a group's candidate is known its row is
+            // requested, so the winner's row is already on its way when the argmax is done
+            unsigned long long best = kNoCandidate;
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f, r5 = 0.f;
             bool timed_out = false;
             for (int q = lane; q < G; q += 64) {
                 unsigned long long gran;
@@ -290,7 +293,12 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(cons
                 const unsigned idx = (unsigned)(gran >> 32) & kIdxMask;
                 if (idx != kIdxMask) {
                     const float v = __builtin_bit_cast(float, (unsigned)(gran & 0xffffffffu));
-                    best = better(best, Best{__builtin_fabsf(v), v, (int)idx});
+                    const unsigned long long c = candidate_key(v, (int)idx);
+                    if (c > best) {
+                        best = c;
+                        const float* p = a.pts + (int64_t)idx * a.ld;    // read-only during the loop
+                        r0 = p[0]; r1 = p[1]; r2 = p[2]; r3 = p[3]; r4 = p[4]; r5 = p[5];
+                    }
                 }
             }
             if (__any(timed_out)) {
@@ -299,22 +307,21 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(cons
                     abort_flag = 1;
                 }
             }
+            // wave argmax of the 64-bit key (two dwords per step instead of three values)
+            unsigned long long wbest = best;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
-                Best o;
-                o.a = __shfl_xor(best.a, off, 64);
-                o.v = __shfl_xor(best.v, off, 64);
-                o.idx = __shfl_xor(best.idx, off, 64);
-                best = better(best, o);
+                const unsigned long long o = __shfl_xor(wbest, off, 64);
+                wbest = o > wbest ? o : wbest;
             }
-            if (lane == 0) global_best = best;
+            if (best == wbest && best != kNoCandidate) {          // exactly one lane: keys are unique per point
+                win_row[0] = r0; win_row[1] = r1; win_row[2] = r2; win_row[3] = r3; win_row[4] = r4; win_row[5] = r5;
+                win_row[6] = (best & 1ull) ? -1.f : 1.f;
+                win_idx = (int)(0x7fffffffu - (unsigned)((best & 0xffffffffull) >> 1));
+            }
         }
         __syncthreads();
         if (abort_flag) break;
-        const Best gb = global_best;
-        cur = __builtin_amdgcn_readfirstlane(gb.idx);
-        cur_sign = (gb.v < 0.f) ? -1.f : 1.f;
-        // global_best / slots_l are rewritten only after the next step's first barrier
     }
 
 #pragma unroll
@@ -369,6 +376,8 @@ int dnp_point_greedy_f32(float* pts, int64_t N, int64_t ld_pts, int64_t start, f
     bool multi = N > 2048;
     if (force && force[0] == '1') multi = true;
     if (force && force[0] == '0' && N <= (int64_t)kGreedyThreads * 24) multi = false;
+    if (workspace && workspace_bytes >= 256)      // status word: 0 = ok (only the multi-workgroup form can set it)
+        DNP_CHECK_HIP(hipMemsetAsync(workspace, 0, 256, st));
     if (!multi) {
 #define DNP_LAUNCH_GREEDY(P)                                                                                   \
     hipLaunchKernelGGL((point_greedy_kernel<P>), dim3(1), dim3(kGreedyThreads), 0, st, pts, N, ld_pts, (int)start, \
