@@ -572,3 +572,23 @@ def test_G13_hand_point_and_patch_propagation(dev):
     assert np.array_equal((tr["sigma"] < 0)[tr["order"]], g["flipped_patch"])
     assert np.allclose(tr["chosen"], g["chosen_patch"], rtol=2e-4)
     assert np.array_equal(((work.cpu()[:, 3:] * pc_patch[:, 3:]).sum(-1) > 0).numpy(), g["sign_patch"])
+
+
+# ---- float64 clouds through the per-point driver (the socket path) -----------------------------------------
+@pytest.mark.parametrize("tag", ["sub1000_n", "sub1000_d", "sub3000_n", "sub3000_d"])
+def test_G14_float64_cloud_point_propagation(dev, tag):
+    """The reference propagates a float64 cloud in fp64 (util.npxyz2tensor feeds float64).  The persistent kernel
+    evaluates in fp32 whatever the input dtype; on the goldens it reproduces the reference's fp64 visit order and
+    signs, returns float64, and only ever multiplies normals by +-1 (so the float64 payload stays exact)."""
+    g = load_golden("G14_point_propagation_f64")
+    name, dflag = tag.split("_")
+    cloud = t(g[f"pc_{name}"])
+    assert cloud.dtype == torch.float64
+    pts = cloud.clone().to(dev)
+    out = fu.strongest_field_propagation_points(pts, diffuse=(dflag == "d"), starting_point=0)
+    assert out.dtype == torch.float64 and out.data_ptr() == pts.data_ptr()
+    order = fu.strongest_field_propagation_points.last_trace["order"].cpu().numpy()
+    assert np.array_equal(order, g[f"order_{tag}"])
+    res = pts.cpu()
+    assert np.array_equal(((res[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g[f"sign_{tag}"])
+    assert torch.equal(res[:, 3:].abs(), cloud[:, 3:].abs()) and torch.equal(res[:, :3], cloud[:, :3])

@@ -476,6 +476,34 @@ def g13(fu, util):
     save("G13_hand", **out)
 
 
+def g14(fu, util):
+    """Per-point propagation on a float64 cloud (the socket path, util.py:71-77 -> field_utils.py:353-388 in
+    fp64): 1000-point ok.xyz subsample and a 3000-point one, visit order + signs."""
+    base = np.load(os.path.join(OUT, "G8_point_propagation.npz"))
+    out = {}
+    for name, cloud in (("sub1000", torch.from_numpy(base["pc_sub1000"]).double()),
+                        ("sub3000", torch.from_numpy(base["pc_full"])[::3][:3000].clone().double())):
+        for diffuse in (False, True):
+            order = []
+            orig_fg = fu.field_grad
+
+            def rec_fg(sources, means, *a, **k):
+                order.append(sources.storage_offset() // 6)
+                return orig_fg(sources, means, *a, **k)
+
+            fu.field_grad = rec_fg
+            try:
+                pts = fu.strongest_field_propagation_points(cloud.clone(), diffuse=diffuse, starting_point=0)
+            finally:
+                fu.field_grad = orig_fg
+            assert pts.dtype == torch.float64
+            tag = f"{name}_{'d' if diffuse else 'n'}"
+            out[f"order_{tag}"] = np.array(order)
+            out[f"sign_{tag}"] = ((pts[:, 3:] * cloud[:, 3:]).sum(-1) > 0)
+        out[f"pc_{name}"] = cloud
+    save("G14_point_propagation_f64", **out)
+
+
 def make_inference_shim():
     """inference_utils.py imports models/ (torch_geometric, absent offline) at module level.
     Only its pure-torch fix_n_filter is on the path; load that one function's source object by
@@ -491,7 +519,7 @@ def make_inference_shim():
     spec.loader.exec_module(mod)
 
 
-ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13)
+ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13, G14=g14)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
