@@ -1,9 +1,6 @@
 """End-to-end runs of the caller counterparts (orient_pointcloud / orient_large / orient_simple /
 reference_orientation / dipole_api) on the reference's clouds, checked against the oracle running the
 same stages on the CPU.  GPU only."""
-import argparse
-from pathlib import Path
-
 import numpy as np
 import pytest
 import torch

@@ -12,7 +12,6 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import csr_to_list, load_golden
-from dipole_normal_prop_amd import field_utils as fu
 from dipole_normal_prop_amd import parallel
 from oracle import dipole_oracle as O
 

@@ -4,8 +4,6 @@ inputs, and size-independent properties at the BASELINE sizes.  Run with `-m gpu
 
 Tolerances: field values within 1e-5 relative to the per-target vector norm in
 fp32 (1e-12 in fp64); sign decisions, visit orders and flip vectors identical."""
-import ctypes
-
 import numpy as np
 import pytest
 import torch

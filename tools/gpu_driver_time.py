@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end timing of the patch drivers on the 100k sphere / fandisk (developer tool)."""
 import os, sys, time, cProfile, pstats
-import numpy as np, torch
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from dipole_normal_prop_amd import field_utils as fu
