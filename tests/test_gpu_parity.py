@@ -590,3 +590,24 @@ def test_G14_float64_cloud_point_propagation(dev, tag):
     res = pts.cpu()
     assert np.array_equal(((res[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g[f"sign_{tag}"])
     assert torch.equal(res[:, 3:].abs(), cloud[:, 3:].abs()) and torch.equal(res[:, :3], cloud[:, :3])
+
+
+def test_point_propagation_multi_workgroup_two_points_per_lane(dev):
+    """140 000 points: 256 workgroups x 512 lanes x 2 points per lane in the persistent multi-workgroup form.
+    A sphere with 30 % of the normals flipped comes back consistently oriented; the visit order is a
+    permutation that starts at the requested point; a second run is bit-identical."""
+    gen = torch.Generator().manual_seed(33)
+    x = torch.randn(140000, 3, generator=gen)
+    n = x / x.norm(dim=-1, keepdim=True)
+    pc = torch.cat([n * 0.5, n], dim=1)
+    scr = pc.clone()
+    scr[torch.rand(140000, generator=gen) < 0.3, 3:] *= -1
+    a = scr.clone().to(dev)
+    fu.strongest_field_propagation_points(a, diffuse=True, starting_point=4242)
+    oa = fu.strongest_field_propagation_points.last_trace["order"].cpu()
+    assert int(oa[0]) == 4242 and torch.equal(torch.sort(oa).values, torch.arange(140000))
+    agree = ((a.cpu()[:, 3:] * pc[:, 3:]).sum(-1) > 0).float().mean().item()
+    assert agree in (0.0, 1.0)
+    b = scr.clone().to(dev)
+    fu.strongest_field_propagation_points(b, diffuse=True, starting_point=4242)
+    assert torch.equal(a, b)
