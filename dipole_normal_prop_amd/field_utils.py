@@ -442,11 +442,18 @@ def _batched_patch_propagation(work: torch.Tensor, patches: List[torch.Tensor], 
 
 
 def _balanced_blocks(sizes: np.ndarray, world: int) -> np.ndarray:
-    """Cut 0..P into `world` contiguous blocks with near-equal total size; returns world+1 bounds."""
+    """Cut 0..P into `world` contiguous blocks of patches; returns world+1 bounds.  Equal counts when that
+    leaves the pair work within 5 % of balanced (uniform patch sizes: the all-gather then needs no padding),
+    otherwise cuts at equal cumulative size."""
     P = len(sizes)
     if world <= 1:
         return np.array([0, P])
     csum = np.concatenate([[0], np.cumsum(sizes)])
+    if P % world == 0:
+        even = np.arange(world + 1) * (P // world)
+        work = np.diff(csum[even])
+        if work.max() <= 1.05 * csum[-1] / world:
+            return even.astype(np.int64)
     targets = csum[-1] * np.arange(1, world) / world
     cuts = np.searchsorted(csum, targets, side="left")
     return np.concatenate([[0], np.clip(cuts, 0, P), [P]]).astype(np.int64)

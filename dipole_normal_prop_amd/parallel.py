@@ -41,6 +41,11 @@ def gather_rows(W_local: torch.Tensor, bounds: np.ndarray, group=None) -> torch.
         return W_local
     P = W_local.shape[1]
     rows = np.diff(bounds)
+    if int(rows.min()) == int(rows.max()) and not _host_staged(W_local):
+        # equal blocks (e.g. 256 patches over 8 ranks): gather straight into the final matrix
+        out = torch.empty((int(rows.sum()), P), dtype=W_local.dtype, device=W_local.device)
+        dist.all_gather_into_tensor(out, W_local.contiguous(), group=group)
+        return out
     pad = int(rows.max())
     buf = torch.zeros((pad, P), dtype=W_local.dtype, device=W_local.device)
     buf[: W_local.shape[0]] = W_local
