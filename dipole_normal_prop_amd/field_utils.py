@@ -365,23 +365,15 @@ def greedy_order_from_interactions(W: np.ndarray, start: int):
     return np.array(order), sigma, np.array(chosen)
 
 
-class _HipBackend:
-    """The three device entry points the batched drivers are built from (include/dnp.h)."""
-    slabs = staticmethod(_patch_slabs)
-    interactions = staticmethod(_interaction_rows)
-    combine = staticmethod(_combine)
-
-
 def _batched_patch_propagation(work: torch.Tensor, patches: List[torch.Tensor], start: int, diffuse: bool,
-                               eps: float = 1e-5, want_E: bool = True, shard=None, backend=_HipBackend):
+                               eps: float = 1e-5, want_E: bool = True, shard=None):
     """Core of the batched drivers on a device cloud `work[N,6]` (normals already weight-scaled).
 
     Returns (order, sigma, chosen, E, point_patch): E[N,3] is this rank's part of the accumulated field of
     the diffuse form in the caller's point order (None unless want_E and diffuse), point_patch[N] the patch
     id per point (-1 = in no patch).  `shard` = (rank, world, gather_fn): patches are split over ranks in
     contiguous size-balanced blocks, each rank computes its slabs and W rows, gather_fn(rows, bounds)
-    returns the full W on every rank.  `backend` supplies slabs / interactions / combine - the HIP entry
-    points, or an oracle-backed stand-in in the multi-process CPU tests (plumbing only)."""
+    returns the full W on every rank."""
     dev = work.device
     N, P = work.shape[0], len(patches)
     off, idx = _csr(patches, dev)
@@ -408,8 +400,8 @@ def _batched_patch_propagation(work: torch.Tensor, patches: List[torch.Tensor], 
     W_rows, kept = [], None
     for b0 in range(p_lo, p_hi, batch):
         b1 = min(b0 + batch, p_hi)
-        dE = backend.slabs(work, off, idx, point_patch, b0, b1, eps)
-        W_rows.append(backend.interactions(dE, work, off, idx))
+        dE = _patch_slabs(work, off, idx, point_patch, b0, b1, eps)
+        W_rows.append(_interaction_rows(dE, work, off, idx))
         if keep:
             kept = dE
         else:
@@ -426,13 +418,13 @@ def _batched_patch_propagation(work: torch.Tensor, patches: List[torch.Tensor], 
         coef = torch.tensor([sigma[k] for k in mine], dtype=torch.float32, device=dev)
         if keep and kept is not None:
             slab = torch.tensor([k - p_lo for k in mine], dtype=torch.int64, device=dev)
-            backend.combine(kept, coef, slab, E, False)
+            _combine(kept, coef, slab, E, False)
         else:
             for b0 in range(p_lo, p_hi, batch):
                 b1 = min(b0 + batch, p_hi)
-                dE = backend.slabs(work, off, idx, point_patch, b0, b1, eps)
+                dE = _patch_slabs(work, off, idx, point_patch, b0, b1, eps)
                 sel = [k for k in mine if b0 <= k < b1]
-                backend.combine(dE, torch.tensor([sigma[k] for k in sel], dtype=torch.float32, device=dev),
+                _combine(dE, torch.tensor([sigma[k] for k in sel], dtype=torch.float32, device=dev),
                          torch.tensor([k - b0 for k in sel], dtype=torch.int64, device=dev), E, True)
                 del dE
     if E is not None:

@@ -73,33 +73,22 @@ def reduce_field(E_partial: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def sharded_patch_propagation(pts: torch.Tensor, patches, all_patches, diffuse=False, weights=None,
-                              start_patch: Optional[int] = None, backend=None):
+                              start_patch: Optional[int] = None):
     """strongest_field_propagation (field_utils.py:286-348) with the per-patch fields sharded over
     the ranks of the default process group.  Every rank must call it with the same arguments; every
-    rank ends with the same oriented normals in `pts` (in place).
-
-    `backend` (default: the HIP entry points) supplies slabs / interactions / combine; the CPU tests
-    inject an oracle-backed stand-in to exercise the partition / gather / reduce plumbing under gloo."""
+    rank ends with the same oriented normals in `pts` (in place)."""
     from . import field_utils as fu
 
     rank, size = world()
     with torch.no_grad():
         if len(all_patches) == 0:
             return
-        if backend is None:
-            work, w = fu._prepare_work(pts, weights)
-            backend = fu._HipBackend
-        else:
-            work = pts.detach().clone().float()
-            w = None
-            if weights is not None:
-                w = weights.detach().float().clamp(0.1, 1)
-                work[:, 3:] = work[:, 3:] * w[:, None]
+        work, w = fu._prepare_work(pts, weights)
         dev = work.device
         if start_patch is None:
             start_patch = fu._flattest_patch(work, [p.to(dev) for p in all_patches])
         order, sigma, chosen, E, point_patch = fu._batched_patch_propagation(
-            work, list(all_patches), int(start_patch), diffuse, shard=(rank, size, gather_rows), backend=backend)
+            work, list(all_patches), int(start_patch), diffuse, shard=(rank, size, gather_rows))
         if diffuse and E is not None:
             E = reduce_field(E)
         sig = torch.tensor(sigma, dtype=torch.float32, device=dev)

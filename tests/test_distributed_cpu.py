@@ -16,11 +16,14 @@ from dipole_normal_prop_amd import parallel
 from oracle import dipole_oracle as O
 
 
-class OracleBackend:
-    """CPU stand-in for dnp_patch_fields_f32 / dnp_interactions_f32 / dnp_combine_fields_f32."""
+class OracleStandIn:
+    """CPU stand-ins for the three device entry wrappers (dnp_patch_fields_f32 / dnp_interactions_f32 /
+    dnp_combine_fields_f32).  The worker processes of this test patch them into field_utils so that the
+    partition / gather / reduce plumbing of the N>1 path can run without a GPU; the product code itself has
+    no such switch."""
 
     @staticmethod
-    def slabs(work, off, idx, point_patch, b0, b1, eps):
+    def slabs(work, off, idx, point_patch, b0, b1, eps, extent=None):
         N = work.shape[0]
         idx = torch.arange(N) if idx is None else idx        # None: cloud sorted by patch
         dE = torch.zeros(b1 - b0, N, 3)
@@ -64,8 +67,11 @@ def _worker(rank, world, port, q):
         torch.set_num_threads(2)
         cloud, patches = _case()
         pts = cloud.clone()
-        parallel.sharded_patch_propagation(pts, list(enumerate(patches)), patches, diffuse=True, start_patch=3,
-                                           backend=OracleBackend)
+        from dipole_normal_prop_amd import field_utils as fu
+        fu._patch_slabs, fu._interaction_rows, fu._combine = OracleStandIn.slabs, OracleStandIn.interactions, \
+            OracleStandIn.combine
+        fu._prepare_work = lambda p, w: (p.detach().clone().float(), None)       # CPU working copy (no weights here)
+        parallel.sharded_patch_propagation(pts, list(enumerate(patches)), patches, diffuse=True, start_patch=3)
         tr = parallel.sharded_patch_propagation.last_trace
         q.put((rank, pts[:, 3:].numpy().copy(), tr["order"].copy(), tr["sigma"].copy()))
     finally:
