@@ -87,6 +87,38 @@ def cpu_baseline(pc_cpu, seconds_target=15.0):
                       f"{best_threads} threads (best of 8/16/32/64 on {avail} visible CPUs)"}
 
 
+def other_configs(dev, fu, pts_sorted, patch_ranges):
+    """The remaining BASELINE configs, timed in the same run (N = 1 only; reported, not the headline):
+    config 1 ok.xyz per-point propagation, config 2 fandisk all-pairs field, config 4's whole greedy driver."""
+    out = {}
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    gdir = os.path.join(ROOT, "tests", "golden")
+    try:
+        fandisk = torch.from_numpy(np.load(os.path.join(gdir, "G5_fandisk_allpairs.npz"))["pc"]).to(dev)
+        t = timed(lambda: fu.field_grad(fandisk, fandisk), 20)
+        out["config2_fandisk_allpairs"] = {"points": int(fandisk.shape[0]), "us_per_call": t * 1e6,
+                                           "pairs_per_s": fandisk.shape[0] ** 2 / t}
+        ok = torch.from_numpy(np.load(os.path.join(gdir, "G8_point_propagation.npz"))["pc_full"])
+        t = timed(lambda: fu.strongest_field_propagation_points(ok.clone().to(dev), diffuse=True), 3)
+        out["config1_ok_point_propagation"] = {"points": int(ok.shape[0]), "ms": t * 1e3,
+                                               "us_per_step": t / ok.shape[0] * 1e6}
+    except FileNotFoundError:
+        pass
+    t = timed(lambda: fu.strongest_field_propagation(pts_sorted.clone(), list(enumerate(patch_ranges)), patch_ranges,
+                                                     diffuse=True, start_patch=0), 5)
+    out["config4_patch_driver_end_to_end"] = {"points": N_POINTS, "patches": N_PATCHES, "ms": t * 1e3}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,6 +236,9 @@ def main():
                           "patches": N_PATCHES, "pairs_per_step": pairs_total,
                           "parallelism": f"patch-sharded x{world}, RCCL all-gather of W rows"},
                "roofline": roofline, "hbm": hbm, "signs_ok": signs_ok}
+        if world == 1 and not (fake > 1):
+            ranges = [torch.arange(int(off[k]), int(off[k + 1]), device=dev) for k in range(N_PATCHES)]
+            out["other_configs"] = other_configs(dev, fu, pts, ranges)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pc_cpu)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
