@@ -87,9 +87,12 @@ def cpu_baseline(pc_cpu, seconds_target=15.0):
                       f"{best_threads} threads (best of 8/16/32/64 on {avail} visible CPUs)"}
 
 
-def other_configs(dev, fu, pts_sorted, patch_ranges):
+def other_configs(dev, fu, util, pts_sorted, patch_ranges):
     """The remaining BASELINE configs, timed in the same run (N = 1 only; reported, not the headline):
-    config 1 ok.xyz per-point propagation, config 2 fandisk all-pairs field, config 4's whole greedy driver."""
+    config 1 ok.xyz per-point propagation (fp32 file path and the fp64 socket path), config 2 fandisk all-pairs
+    field, config 3 boxunion representative propagation (the reference's own 369 patches / representatives),
+    config 4's whole greedy driver, config 5's source -> target transfer at S = T = 100 000 (fp32; the fp16
+    wording of BASELINE is costed and rejected in DESIGN.md section 4)."""
     out = {}
 
     def timed(fn, reps):
@@ -111,11 +114,37 @@ def other_configs(dev, fu, pts_sorted, patch_ranges):
         t = timed(lambda: fu.strongest_field_propagation_points(ok.clone().to(dev), diffuse=True), 3)
         out["config1_ok_point_propagation"] = {"points": int(ok.shape[0]), "ms": t * 1e3,
                                                "us_per_step": t / ok.shape[0] * 1e6}
+        ok64 = ok.double()
+        t = timed(lambda: fu.strongest_field_propagation_points(ok64.clone().to(dev), diffuse=True), 2)
+        out["config1_ok_point_propagation_f64"] = {"points": int(ok.shape[0]), "ms": t * 1e3,
+                                                   "us_per_step": t / ok.shape[0] * 1e6}
+        g15 = np.load(os.path.join(gdir, "G15_boxunion_config3.npz"))
+        cloud = torch.from_numpy(g15["pc"]).clone()
+        cloud[~torch.from_numpy(g15["prefilter_sign"]), 3:] *= -1
+        cloud = cloud.to(dev)
+        i64 = lambda a: torch.from_numpy(a.astype(np.int64)).to(dev)
+        reps = [(i64(g15["rep_idx"][g15["rep_off"][k]:g15["rep_off"][k + 1]]),
+                 i64(g15["rest_idx"][g15["rest_off"][k]:g15["rest_off"][k + 1]])) for k in range(len(g15["rep_off"]) - 1)]
+        t = timed(lambda: fu.strongest_field_propagation_reps(cloud.clone(), reps, diffuse=True), 3)
+        nrep = int(g15["rep_off"][-1])
+        out["config3_boxunion_reps_propagation"] = {
+            "points": int(cloud.shape[0]), "patches": len(reps), "representatives": nrep, "ms": t * 1e3,
+            "pairs": float(nrep) ** 2 + float(nrep) * (cloud.shape[0] - nrep),
+            "note": "reference's partition/representatives (tests/golden/G15); reference CPU run: 360-440 s"}
+        t = timed(lambda: util.divide_pc(cloud[:, :3], 41, min_patch=100), 5)
+        out["config3_boxunion_partition_and_merge"] = {"ms": t * 1e3, "patches": len(reps)}
     except FileNotFoundError:
         pass
     t = timed(lambda: fu.strongest_field_propagation(pts_sorted.clone(), list(enumerate(patch_ranges)), patch_ranges,
-                                                     diffuse=True, start_patch=0), 5)
+                                                     diffuse=True), 5)
     out["config4_patch_driver_end_to_end"] = {"points": N_POINTS, "patches": N_PATCHES, "ms": t * 1e3}
+    t = timed(lambda: fu.field_grad(pts_sorted, pts_sorted), 5)
+    out["allpairs_100k_field_grad"] = {"points": N_POINTS, "ms": t * 1e3, "pairs_per_s": float(N_POINTS) ** 2 / t}
+    g = torch.Generator().manual_seed(3)
+    tgt = (pts_sorted[:, :3].cpu() + 1e-3 * torch.randn(N_POINTS, 3, generator=g)).to(dev)
+    t = timed(lambda: fu.reference_field(pts_sorted, tgt), 5)
+    out["config5_reference_field_100k_to_100k"] = {"sources": N_POINTS, "targets": N_POINTS, "ms": t * 1e3,
+                                                   "pairs_per_s": float(N_POINTS) ** 2 / t, "dtype": "f32"}
     return out
 
 
@@ -145,15 +174,20 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from dipole_normal_prop_amd import field_utils as fu
-    from dipole_normal_prop_amd import parallel
+    from dipole_normal_prop_amd import parallel, util
 
     pc_cpu = sphere_cloud()
     patches = fibonacci_patches(pc_cpu)
     sizes = np.array([len(p) for p in patches])
     pairs_total = float((sizes * (N_POINTS - sizes)).sum())
+    # whole patches flipped at random (seed 0): the propagation has 256 sign decisions to get right, checked below
+    scramble = (torch.rand(N_PATCHES, generator=torch.Generator().manual_seed(0)) < 0.5).numpy()
+    for k, p in enumerate(patches):
+        if scramble[k]:
+            pc_cpu[p, 3:] *= -1
     # layout: the cloud sorted by patch (what the drivers do, field_utils._batched_patch_propagation), so a
     # patch is a contiguous row range and every slab / interaction access is coalesced
-    off, idx = fu._csr(patches, dev)
+    off, idx, _ = util.patch_csr(patches, dev)
     pts = pc_cpu.to(dev)[idx].contiguous()
     point_patch = torch.repeat_interleave(torch.arange(N_PATCHES, device=dev), off[1:] - off[:-1])
     idx = None
@@ -188,7 +222,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
-    value = pairs_total * args.steps / elapsed
+    # developer aid BENCH_FAKE_WORLD: only one rank's share was computed, so only that share is credited
+    value = (my_pairs if (fake > 1 and world == 1) else pairs_total) * args.steps / elapsed
 
     # ---- roofline of the dominant kernel: HIP events around the pair-kernel launch alone ------------------
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -202,28 +237,40 @@ def main():
     launch_pairs = float((sizes[p_lo:p_hi] * N_POINTS).sum())
     tflops = launch_pairs * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
     algo_bytes = 36.0 * N_POINTS + 12.0 * N_POINTS * (p_hi - p_lo)   # cloud read once + [K,N,3] slab written once
-    roofline = {"bound": "valu", "kernel": "pair_kernel<float,float,field,KT=4,kFast>", "achieved": tflops,
+    roofline = {"bound": "valu", "achieved": tflops,
                 "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VALU_PEAK_TFLOPS,
                 "traffic": None, "launch_ms": k_ms, "flop_per_pair": FLOP_PER_PAIR,
                 "pairs_per_launch": launch_pairs,
-                "note": "FP32 vector ALU binds (no MFMA on this path); peak equals the dense f32 MFMA peak"}
+                "timed": "HIP events around dnp_patch_fields_f32 (one pair_kernel launch) on torch's current stream",
+                "note": "FP32 vector ALU binds (no MFMA on this path); peak equals the dense f32 MFMA peak; 33 flop "
+                        "per pair is the exact chain's count - pairs that take the far-field chain execute 45"}
     hbm = {"bound": "hbm", "achieved": algo_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
            "traffic": None}
-    prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(prof):
-        try:
-            tr = json.load(open(prof))
-            roofline["traffic"] = hbm["traffic"] = tr.get("hbm_bytes_per_launch")
-        except Exception:
-            pass
+    # HBM traffic cannot be read inside the run (PMC counters need rocprofv3): it is PROFILE-DERIVED, from the
+    # committed summary of `rocprofv3 --pmc` passes over this same command, and says so
+    for prof_name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        prof = os.path.join(ROOT, "profiles", prof_name)
+        if os.path.exists(prof):
+            try:
+                tr = json.load(open(prof))
+                roofline["traffic"] = hbm["traffic"] = tr.get("hbm_bytes_per_launch")
+                roofline["traffic_source"] = hbm["traffic_source"] = f"profile-derived: profiles/{prof_name}"
+                roofline["kernel"] = tr.get("kernel")
+                break
+            except Exception:
+                pass
 
-    # sanity: the gathered matrix must be the full P x P on every rank and orient the sphere
+    # sanity: the gathered matrix must be the full P x P on every rank, and the greedy loop on it must undo the
+    # patch scramble: every scrambled patch ends with one sign, every untouched patch with the other
     signs_ok = None
     if not (fake > 1 and world == 1):
         assert W.shape == (N_PATCHES, N_PATCHES)
-        order, sigma, _ = fu.greedy_order_from_interactions(W.cpu().numpy(), 0)
-        signs_ok = bool(np.all(sigma == 1.0))    # unflipped outward sphere: nobody flips
+        _, sigma, _ = fu._greedy_on_device(W, torch.zeros(1, dtype=torch.int64, device=dev))
+        sigma = sigma.cpu().numpy()
+        flipped_sign, kept_sign = sigma[scramble], sigma[~scramble]
+        signs_ok = bool(np.all(flipped_sign == flipped_sign[0]) and np.all(kept_sign == kept_sign[0])
+                        and flipped_sign[0] == -kept_sign[0])
 
     out = None
     if rank == 0:
@@ -231,17 +278,21 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
-               "config": {"workload": "synthetic 100k-point sphere (seed 1234), 256 Fibonacci patches, all per-patch "
-                                      "fields + interaction matrix (BASELINE config 4)", "points": N_POINTS,
+               "config": {"workload": "synthetic 100k-point sphere (seed 1234), 256 Fibonacci patches (whole patches "
+                                      "sign-scrambled, seed 0), all per-patch fields + interaction matrix (BASELINE "
+                                      "config 4)", "points": N_POINTS,
                           "patches": N_PATCHES, "pairs_per_step": pairs_total,
                           "parallelism": f"patch-sharded x{world}, RCCL all-gather of W rows"},
                "roofline": roofline, "hbm": hbm, "signs_ok": signs_ok}
+        if fake > 1 and world == 1:
+            out["fake_world"] = fake          # NOT a measurement of `fake` GPUs: one rank's share on one GPU
         if world == 1 and not (fake > 1):
-            ranges = [torch.arange(int(off[k]), int(off[k + 1]), device=dev) for k in range(N_PATCHES)]
-            out["other_configs"] = other_configs(dev, fu, pts, ranges)
+            ranges = util.PatchList(torch.arange(N_POINTS, device=dev), sizes)
+            out["other_configs"] = other_configs(dev, fu, util, pts, ranges)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pc_cpu)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        fu.flush_warnings()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -22,9 +22,9 @@ SIGNATURES = {
     "dnp_field_grad_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "dnp_potential_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "dnp_field_grad_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, ctypes.c_float,
-                                          _c_i64, _c_p, _c_i64, ctypes.c_int, ctypes.c_int, _c_p, _c_sz, _c_p]),
+                                          _c_i64, _c_p, _c_i64, ctypes.c_int, ctypes.c_int, _c_p, _c_p, _c_sz, _c_p]),
     "dnp_field_grad_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, ctypes.c_double,
-                                          _c_i64, _c_p, _c_i64, ctypes.c_int, ctypes.c_int, _c_p, _c_sz, _c_p]),
+                                          _c_i64, _c_p, _c_i64, ctypes.c_int, ctypes.c_int, _c_p, _c_p, _c_sz, _c_p]),
     "dnp_potential_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p,
                                          _c_i64, _c_p, _c_sz, _c_p]),
     "dnp_potential_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p,
@@ -38,10 +38,18 @@ SIGNATURES = {
     "dnp_xie_pairs_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, ctypes.c_double, ctypes.c_int,
                                          _c_p, _c_p]),
     "dnp_xie_order_f32": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p]),
-    "dnp_point_greedy_workspace_bytes": (_c_sz, [_c_i64]),
+    "dnp_point_greedy_workspace_bytes": (_c_sz, [_c_i64, ctypes.c_int]),
     "dnp_point_greedy_max_points": (ctypes.c_int, []),
     "dnp_point_greedy_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_i64, ctypes.c_float, ctypes.c_int, _c_p, _c_p,
-                                            _c_p, _c_sz, _c_p]),
+                                            ctypes.c_int, ctypes.c_int, _c_p, _c_sz, _c_p]),
+    "dnp_point_greedy_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_i64, ctypes.c_double, ctypes.c_int, _c_p, _c_p,
+                                            ctypes.c_int, ctypes.c_int, _c_p, _c_sz, _c_p]),
+    "dnp_patch_pca_f32": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p]),
+    "dnp_patch_pca_f64": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p]),
+    "dnp_patch_greedy_max_patches": (ctypes.c_int, []),
+    "dnp_patch_greedy": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "dnp_combine_signed_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, ctypes.c_int, _c_p]),
+    "dnp_merge_cells": (ctypes.c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p]),
 }
 
 _lib = None

@@ -5,6 +5,8 @@
 // pair_kernel over (target tiles x chunks) and then reduce_kernel, which sums the chunks of
 // each leaf in fp64, zeroes non-finite leaf components (field_utils.py:110-115 / :53-54) and
 // adds the leaves.
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "dnp_common.h"
@@ -20,11 +22,9 @@ namespace dnp {
 static inline int64_t min_chunk(int64_t S) { const int64_t m = S / 64; return m < 64 ? 64 : (m > DNP_MINCHUNK_CAP ? DNP_MINCHUNK_CAP : m); }
 constexpr int kKTLarge = 4;                // targets per lane for large target sets (swept: 4 x 2 accumulator sets)
 constexpr int64_t kTilesForLarge = 64;     // ... used once that still leaves >= 64 target tiles
-#ifndef DNP_WANT_BLOCKS
-#define DNP_WANT_BLOCKS 8192
-#endif
-constexpr int64_t kWantBlocks = DNP_WANT_BLOCKS;  // ~32 workgroups per CU keeps the tail short (tuned: 2048..16384)
 constexpr size_t kSlabCap = (size_t)1 << 30;  // bytes of partial slab per round
+// workgroups of 256 threads a CU holds at once: KT = 4 needs 134 VGPRs (3 waves per SIMD), KT = 1 fits 8
+constexpr int kResidentLarge = 3, kResidentSmall = 8;
 
 struct Plan {
     // one entry per round; every round is a run of whole leaves
@@ -48,23 +48,82 @@ static void split_leaves(int64_t lo, int64_t hi, int64_t max_pts, std::vector<in
     }
 }
 
+static int compute_units() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        else {
+            (void)hipGetLastError();
+            cus = 256;                       // MI355X; planning must also work where no device is visible
+        }
+    }
+    return cus;
+}
+
+// Number of source chunks for one launch.  All workgroups of a launch do the same amount of work, so the launch
+// runs in ceil(blocks / resident) rounds of equal length: pick the chunk count that wastes the least of the last
+// round while keeping the fp64 partial slab (24 B per target and chunk, written once and read once) small.
+static int64_t choose_chunks(int64_t S, int64_t T, int64_t t_tiles, int kt, int64_t n_leaves, int64_t cap) {
+    const int64_t slots = (int64_t)compute_units() * (kt == kKTLarge ? kResidentLarge : kResidentSmall);
+    const int64_t longest = S / min_chunk(S) > 0 ? S / min_chunk(S) : 1;   // most chunks the minimum length allows
+    int64_t hi = cap < longest ? cap : longest;
+    if (hi < n_leaves) hi = n_leaves;
+    int64_t lo = n_leaves;
+    double best_cost = 0;
+    int64_t best = lo;
+    for (int64_t n = lo; n <= hi; ++n) {
+        const int64_t blocks = t_tiles * n;
+        const double rounds = (double)ceil_div(blocks, slots);
+        // one round = one workgroup's S/n sources x (256 kt) targets at the chip rate / slots; the slab costs
+        // 48 bytes per target and chunk at ~4 TB/s; a round also pays ~1 us of launch/drain
+        const double t_pairs = rounds * ((double)S / n) * (256.0 * kt) / (2.1e12 / (double)slots);
+        const double t_slab = (n > 1 ? 48.0 * (double)T * n / 4e12 : 0.0);
+        const double cost = t_pairs + t_slab + rounds * 1e-6;
+        if (n == lo || cost < best_cost) { best_cost = cost; best = n; }
+    }
+    return best;
+}
+
 static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem) {
     Plan plan;
     std::vector<int64_t> cuts;  // leaf end offsets
     if (S > 0) split_leaves(0, S, max_pts, cuts);
     // small problems are latency bound: prefer many short workgroups (1 target per lane, chunks down to 64
-    // sources); large ones amortise the LDS reads over 2 targets per lane
+    // sources); large ones amortise the LDS reads over 4 targets per lane
     plan.kt = (T >= (int64_t)kBlock * kKTLarge * kTilesForLarge) ? kKTLarge : 1;
     const int64_t t_tiles = ceil_div(T > 0 ? T : 1, (int64_t)kBlock * plan.kt);
     const int64_t n_leaves = (int64_t)cuts.size();
-    int64_t want = ceil_div(kWantBlocks, t_tiles);
-    if (want < n_leaves) want = n_leaves;
     // chunk cap per round from the slab budget (at least one)
     int64_t cap = (int64_t)(kSlabCap / ((size_t)(T > 0 ? T : 1) * nc * elem));
     if (cap > kMaxChunks) cap = kMaxChunks;
     if (cap < 1) cap = 1;
+    int64_t want = choose_chunks(S, T, t_tiles, plan.kt, n_leaves, cap >= n_leaves ? cap : kMaxChunks);
+    if (want < n_leaves) want = n_leaves;
     // keep all leaves in ONE round whenever they fit: a round is two launches
     if (n_leaves <= cap && want > cap) want = cap;
+
+    // hand the chunks to the leaves in proportion to their length (largest remainder), at least one each
+    std::vector<int64_t> per_leaf((size_t)n_leaves, 1);
+    {
+        int64_t lo = 0, given = 0;
+        std::vector<std::pair<double, int64_t>> frac;
+        for (int64_t l = 0; l < n_leaves; ++l) {
+            const double share = (double)want * (double)(cuts[l] - lo) / (double)S;
+            int64_t m = (int64_t)share;
+            if (m < 1) m = 1;
+            per_leaf[(size_t)l] = m;
+            given += m;
+            frac.push_back({share - (double)(int64_t)share, l});
+            lo = cuts[l];
+        }
+        std::sort(frac.begin(), frac.end(), [](const std::pair<double, int64_t>& x, const std::pair<double, int64_t>& y) {
+            return x.first > y.first || (x.first == y.first && x.second < y.second);
+        });
+        for (size_t i = 0; given < want && i < frac.size(); ++i, ++given) per_leaf[(size_t)frac[i].second] += 1;
+    }
 
     Plan::Round cur;
     cur.chunk_off.push_back(0);
@@ -73,7 +132,7 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
     for (int64_t l = 0; l < n_leaves; ++l) {
         const int64_t hi = cuts[l];
         const int64_t len = hi - lo;
-        int64_t m = want * len / S;                     // this leaf's share of the wanted chunks (floor: sum <= want)
+        int64_t m = per_leaf[(size_t)l];
         const int64_t m_max = len / min_chunk(S) > 0 ? len / min_chunk(S) : 1;
         if (m > m_max) m = m_max;
         if (m > cap) m = cap;
@@ -109,6 +168,7 @@ struct ReduceArgs {
     int64_t ld_out;
     int out_scatter;
     int accumulate;
+    int* nonfinite;         // [2] counters of inf / nan leaf components zeroed, or nullptr
     int n_leaves;
     int32_t leaf_first[kMaxChunks + 1];
 };
@@ -134,7 +194,8 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs<F> a) {
         }
         const F f = (F)s;
         // E_total[E_total.isinf()] = 0; E_total[E_total.isnan()] = 0   (per leaf, per component)
-        total += (__builtin_isfinite(f)) ? (double)f : 0.0;
+        if (__builtin_isfinite(f)) total += (double)f;
+        else if (a.nonfinite) atomicAdd(a.nonfinite + (f != f ? 1 : 0), 1);
     }
     const int64_t row = a.out_scatter ? a.tgt_idx[t] : t;
     F* o = a.out + row * a.ld_out + c;
@@ -146,7 +207,7 @@ template <typename F, int MODE>
 static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
                      const F* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
                      F eps, int64_t max_pts, F* out, int64_t ld_out, int out_scatter, int accumulate,
-                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                     int* nonfinite, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     constexpr int NC = (MODE == kField) ? 3 : 1;
     clear_error();
     DNP_REQUIRE(S >= 0 && T >= 0, "negative size S=%lld T=%lld", (long long)S, (long long)T);
@@ -163,7 +224,7 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
         if (!accumulate) {
             ReduceArgs<F> ra{};
             ra.partial = nullptr; ra.T = T; ra.tgt_idx = tgt_idx; ra.out = out; ra.ld_out = ld_out;
-            ra.out_scatter = out_scatter; ra.accumulate = 0; ra.n_leaves = 0;
+            ra.out_scatter = out_scatter; ra.accumulate = 0; ra.nonfinite = nullptr; ra.n_leaves = 0;
             const int64_t n = T * NC;
             hipLaunchKernelGGL((reduce_kernel<F, NC>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, ra);
             DNP_CHECK_HIP(hipGetLastError());
@@ -191,6 +252,7 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
         // one chunk that is also the only leaf of the only round: the pair kernel writes the final rows
         const bool direct = plan.rounds.size() == 1 && n_chunks == 1;
         pa.out = direct ? out : nullptr; pa.ld_out = ld_out; pa.out_scatter = out_scatter; pa.accumulate = accumulate;
+        pa.nonfinite = nonfinite; pa.far_d2 = F(0);
         for (int i = 0; i <= n_chunks; ++i) pa.chunk_off[i] = r.chunk_off[i];
         const dim3 grid((unsigned)t_tiles, (unsigned)n_chunks);
         // eps > 0 (what every caller of the reference passes): the short chain; otherwise the explicit one
@@ -212,7 +274,7 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
 
         ReduceArgs<F> ra{};
         ra.partial = (const double*)workspace; ra.T = T; ra.tgt_idx = tgt_idx; ra.out = out; ra.ld_out = ld_out;
-        ra.out_scatter = out_scatter; ra.accumulate = (accumulate || !first) ? 1 : 0;
+        ra.out_scatter = out_scatter; ra.accumulate = (accumulate || !first) ? 1 : 0; ra.nonfinite = nonfinite;
         ra.n_leaves = (int)r.leaf_first.size() - 1;
         for (int i = 0; i <= ra.n_leaves; ++i) ra.leaf_first[i] = r.leaf_first[i];
         const int64_t n = T * NC;
@@ -243,17 +305,17 @@ size_t dnp_potential_workspace_bytes(int64_t S, int64_t T, int64_t max_pts) {
 int dnp_field_grad_f32(const float* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
                        const float* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
                        float eps, int64_t max_pts, float* out, int64_t ld_out, int out_scatter,
-                       int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+                       int accumulate, int32_t* nonfinite, void* workspace, size_t workspace_bytes, void* stream) {
     return run_pairs<float, kField>(src, S, ld_src, src_idx, tgt, T, ld_tgt, tgt_idx, eps, max_pts, out, ld_out,
-                                    out_scatter, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+                                    out_scatter, accumulate, nonfinite, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int dnp_field_grad_f64(const double* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
                        const double* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
                        double eps, int64_t max_pts, double* out, int64_t ld_out, int out_scatter,
-                       int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+                       int accumulate, int32_t* nonfinite, void* workspace, size_t workspace_bytes, void* stream) {
     return run_pairs<double, kField>(src, S, ld_src, src_idx, tgt, T, ld_tgt, tgt_idx, eps, max_pts, out, ld_out,
-                                     out_scatter, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+                                     out_scatter, accumulate, nonfinite, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int dnp_potential_f32(const float* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
@@ -261,7 +323,7 @@ int dnp_potential_f32(const float* src, int64_t S, int64_t ld_src, const int64_t
                       int64_t max_pts, float* out, int64_t ld_out,
                       void* workspace, size_t workspace_bytes, void* stream) {
     return run_pairs<float, kPotential>(src, S, ld_src, src_idx, tgt, T, ld_tgt, tgt_idx, 0.f, max_pts, out, ld_out,
-                                        0, 0, workspace, workspace_bytes, (hipStream_t)stream);
+                                        0, 0, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int dnp_potential_f64(const double* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
@@ -269,7 +331,7 @@ int dnp_potential_f64(const double* src, int64_t S, int64_t ld_src, const int64_
                       int64_t max_pts, double* out, int64_t ld_out,
                       void* workspace, size_t workspace_bytes, void* stream) {
     return run_pairs<double, kPotential>(src, S, ld_src, src_idx, tgt, T, ld_tgt, tgt_idx, 0.0, max_pts, out, ld_out,
-                                         0, 0, workspace, workspace_bytes, (hipStream_t)stream);
+                                         0, 0, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,6 +1,8 @@
 // dnp_patch.hip - batched per-patch fields (the multi-GPU shard unit), the patch interaction
 // matrix (K3) and the ordered slab combination used by the greedy patch drivers
 // (field_utils.strongest_field_propagation{,_reps}, field_utils.py:207-348).
+#include <math.h>
+
 #include "dnp_common.h"
 #include "pair_kernel.h"
 
@@ -10,6 +12,12 @@ namespace dnp {
 #define DNP_KT 4
 #endif
 constexpr int kPatchKT = DNP_KT;
+// far-field (one transcendental) path for tiles whose sources are far from the wave's targets; the drivers sort
+// the cloud by patch, so both are spatially coherent runs
+#ifndef DNP_FAR
+#define DNP_FAR 1
+#endif
+constexpr bool kPatchFar = DNP_FAR != 0;
 
 // W[k][j] = sum_{t in patch j} dE[k][t] . n_t    - one workgroup per (j, k), fp64 tree reduce.
 __global__ __launch_bounds__(256) void interactions_kernel(const float* __restrict__ dE, int64_t N,
@@ -80,10 +88,12 @@ int dnp_patch_fields_f32(const float* pts, int64_t N, int64_t ld_pts, const int6
         pa.tgt = pts; pa.ld_tgt = ld_pts; pa.tgt_idx = nullptr; pa.T = N;
         pa.chunk_off_dev = patch_off; pa.chunk_base = p_begin + k0; pa.tgt_group = point_patch;
         pa.eps = eps; pa.partial = dE + k0 * N * 3;
+        pa.far_d2 = eps > 0.f ? (float)pow((double)eps / kFarRatio, 2.0 / 3.0) : 0.f;
         const dim3 grid((unsigned)t_tiles, (unsigned)kn);
         const hipStream_t st = (hipStream_t)stream;
         if (eps > 0.f)
-            hipLaunchKernelGGL((pair_kernel<float, float, kField, kPatchKT, kFast>), grid, dim3(kBlock), 0, st, pa);
+            hipLaunchKernelGGL((pair_kernel<float, float, kField, kPatchKT, kFast, kPatchFar>), grid, dim3(kBlock), 0, st,
+                               pa);
         else if (eps == 0.f)
             hipLaunchKernelGGL((pair_kernel<float, float, kField, kPatchKT, kNanCoinc>), grid, dim3(kBlock), 0, st, pa);
         else

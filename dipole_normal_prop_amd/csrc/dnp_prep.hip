@@ -1,0 +1,337 @@
+// dnp_prep.hip - the steps directly in front of / behind the pair kernels in the patch drivers, moved off the
+// host:
+//   dnp_patch_pca_*    per-patch mean + 3x3 covariance + eigen-decomposition in fp64, one workgroup per patch
+//                      (util.pca_eigen_values util.py:495-500, the start-patch rule field_utils.py:230-233 /
+//                      :303-306, inference_utils.fix_n_filter :52-71, util.orient_center util.py:39-44)
+//   dnp_patch_greedy   the greedy loop of field_utils.py:314-324 / :242-254 on the P x P interaction matrix,
+//                      one wavefront, no host round trip
+//   dnp_merge_cells    the order-dependent merge of small voxel cells (util.merge_nodes util.py:448-492);
+//                      sequential by definition, so it is a HOST function on the cell table (a few thousand rows)
+#include <math.h>
+
+#include <unordered_map>
+#include <vector>
+
+#include "dnp_common.h"
+
+namespace dnp {
+
+// ---- deterministic block sum of NV doubles per thread (256 threads): wave tree, then the 4 waves in order ----
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* lds /* [4][NV] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NV; ++c)
+        for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_down(v[c], off, 64);
+    __syncthreads();                                   // previous users of lds are done
+    if (lane == 0)
+#pragma unroll
+        for (int c = 0; c < NV; ++c) lds[wave * NV + c] = v[c];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NV; ++c) v[c] = (lds[0 * NV + c] + lds[1 * NV + c]) + (lds[2 * NV + c] + lds[3 * NV + c]);
+}
+
+// cyclic Jacobi on a symmetric 3x3 (fp64): a -> diag, v -> eigenvectors in columns
+__device__ inline void jacobi3(double a[3][3], double v[3][3]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        const double diag = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
+        if (off == 0.0 || off <= 1e-300 || off < 1e-22 * diag) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (a[p][q] == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                const double apq = a[p][q];
+                a[p][p] -= t * apq;
+                a[q][q] += t * apq;
+                a[p][q] = a[q][p] = 0.0;
+                const int r = 3 - p - q;
+                const double arp = a[r][p], arq = a[r][q];
+                a[r][p] = a[p][r] = c * arp - s * arq;
+                a[r][q] = a[q][r] = s * arp + c * arq;
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = v[k][p], vkq = v[k][q];
+                    v[k][p] = c * vkp - s * vkq;
+                    v[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+template <typename F>
+__global__ __launch_bounds__(256) void patch_pca_kernel(const F* __restrict__ pts, int64_t ld,
+                                                        const int64_t* __restrict__ off,
+                                                        const int64_t* __restrict__ idx, double* __restrict__ mean,
+                                                        double* __restrict__ evals, double* __restrict__ evecs) {
+    __shared__ double red[4 * 6];
+    __shared__ double mu[3];
+    const int64_t p = blockIdx.x, lo = off[p], hi = off[p + 1];
+    const double n = (double)(hi - lo);
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const F* r = pts + (idx ? idx[i] : i) * ld;
+        s[0] += (double)r[0]; s[1] += (double)r[1]; s[2] += (double)r[2];
+    }
+    block_sum<3>(s, red);
+    if (threadIdx.x == 0)
+        for (int c = 0; c < 3; ++c) mu[c] = (hi > lo) ? s[c] / n : 0.0;
+    __syncthreads();
+    const double mx = mu[0], my = mu[1], mz = mu[2];
+    double m2[6] = {0, 0, 0, 0, 0, 0};                  // xx xy xz yy yz zz about the mean
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const F* r = pts + (idx ? idx[i] : i) * ld;
+        const double x = (double)r[0] - mx, y = (double)r[1] - my, z = (double)r[2] - mz;
+        m2[0] += x * x; m2[1] += x * y; m2[2] += x * z; m2[3] += y * y; m2[4] += y * z; m2[5] += z * z;
+    }
+    block_sum<6>(m2, red);
+    if (threadIdx.x != 0) return;
+    double a[3][3], v[3][3];
+    const double inv = (hi > lo) ? 1.0 / n : 0.0;
+    a[0][0] = m2[0] * inv; a[0][1] = a[1][0] = m2[1] * inv; a[0][2] = a[2][0] = m2[2] * inv;
+    a[1][1] = m2[3] * inv; a[1][2] = a[2][1] = m2[4] * inv; a[2][2] = m2[5] * inv;
+    jacobi3(a, v);
+    int o[3] = {0, 1, 2};                               // ascending eigenvalues
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2 - i; ++j)
+            if (a[o[j]][o[j]] > a[o[j + 1]][o[j + 1]]) { const int t = o[j]; o[j] = o[j + 1]; o[j + 1] = t; }
+    for (int c = 0; c < 3; ++c) mean[p * 3 + c] = mu[c];
+    for (int k = 0; k < 3; ++k) {
+        const int col = o[k];
+        evals[p * 3 + k] = a[col][col];
+        // sign convention (an eigenvector's sign is arbitrary; LAPACK's is an implementation detail):
+        // the component of largest magnitude is positive, ties to the lowest index
+        int big = 0;
+        for (int c = 1; c < 3; ++c)
+            if (fabs(v[c][col]) > fabs(v[big][col])) big = c;
+        const double sg = v[big][col] < 0.0 ? -1.0 : 1.0;
+        for (int c = 0; c < 3; ++c) evecs[p * 9 + c * 3 + k] = sg * v[c][col];   // [P][row c][eigen k] as torch's v
+    }
+}
+
+// ---- greedy loop on W: one wavefront, lane l owns patches l, l+64, ... (EPL per lane) -------------------------
+// I_j = sum_{k visited} sigma_k W[k][j]; pick the first maximum of |I_j| over the unvisited patches in patch
+// order (torch.argmax over the reference's `remaining` list, which stays in patch order), flip when I_j < 0.
+template <int EPL>
+__global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restrict__ W, int P,
+                                                          const int64_t* __restrict__ start_ptr,
+                                                          int64_t* __restrict__ order, double* __restrict__ sigma,
+                                                          double* __restrict__ chosen) {
+    const int lane = threadIdx.x;
+    double inter[EPL];
+    unsigned long long visited = 0, negative = 0;        // bit e <-> patch e*64 + lane
+    int cur = (int)start_ptr[0];
+    if (cur < 0 || cur >= P) cur = 0;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        inter[e] = 0.0;
+        if (e * 64 + lane >= P) visited |= 1ull << e;
+    }
+    double s = 1.0;                                       // the start patch is not flipped
+    for (int step = 0; step < P; ++step) {
+        if (lane == 0) order[step] = cur;
+        if ((cur & 63) == lane) {
+            visited |= 1ull << (cur >> 6);
+            if (s < 0.0) negative |= 1ull << (cur >> 6);
+        }
+        const double* row = W + (int64_t)cur * P;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int j = e * 64 + lane;
+            if (j < P) inter[e] += s * row[j];           // s = +-1: the product is exact
+        }
+        if (step + 1 == P) break;
+        // first maximum of |I_j| in patch order; a NaN counts as the maximum, as in torch.argmax
+        double bv = -1.0, bi = 0.0;
+        int bj = 0x7fffffff;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {                  // ascending j within the lane
+            double a = fabs(inter[e]);
+            if (a != a) a = __builtin_huge_val();
+            if (!((visited >> e) & 1ull) && a > bv) { bv = a; bj = e * 64 + lane; bi = inter[e]; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off, 64), oi = __shfl_xor(bi, off, 64);
+            const int oj = __shfl_xor(bj, off, 64);
+            if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; bi = oi; }
+        }
+        cur = bj;                                        // wave-uniform after the butterfly
+        s = (bi < 0.0) ? -1.0 : 1.0;                     // `if interaction[max] < 0: flip`
+        if (lane == 0) chosen[step] = bi;
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int j = e * 64 + lane;
+        if (j < P) sigma[j] = ((negative >> e) & 1ull) ? -1.0 : 1.0;
+    }
+}
+
+// E64[t][c] (+)= sum_k sigma[k] * dE[k][t][c] over the K slabs held here, accumulated in fp64 in slab order.
+// sigma is +-1, so every product is exact; a fp64 sum of a few thousand fp32 values is independent of the
+// order to ~1e-16 relative, hence the same on one GPU and on eight.
+__global__ __launch_bounds__(256) void combine_signed_kernel(const float* __restrict__ dE, int64_t K, int64_t N3,
+                                                             const double* __restrict__ sigma,
+                                                             double* __restrict__ E, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N3) return;
+    double e = accumulate ? E[i] : 0.0;
+    int64_t k = 0;
+    for (; k + 4 <= K; k += 4) {                      // 4 independent loads in flight, added in slab order
+        const float v0 = dE[(k + 0) * N3 + i], v1 = dE[(k + 1) * N3 + i], v2 = dE[(k + 2) * N3 + i],
+                    v3 = dE[(k + 3) * N3 + i];
+        e += sigma[k + 0] * (double)v0; e += sigma[k + 1] * (double)v1;
+        e += sigma[k + 2] * (double)v2; e += sigma[k + 3] * (double)v3;
+    }
+    for (; k < K; ++k) e += sigma[k] * (double)dE[k * N3 + i];
+    E[i] = e;
+}
+
+}  // namespace dnp
+
+using namespace dnp;
+
+extern "C" {
+
+static int patch_pca_check(const void* pts, int64_t ld, const int64_t* off, int64_t P, double* mean, double* evals,
+                           double* evecs) {
+    clear_error();
+    DNP_REQUIRE(P >= 0, "negative P");
+    if (P == 0) return 1;
+    DNP_REQUIRE(pts && off && mean && evals && evecs, "NULL pointer");
+    DNP_REQUIRE(ld >= 3, "ld_pts=%lld < 3", (long long)ld);
+    DNP_REQUIRE(P <= INT32_MAX, "P too large");
+    return DNP_OK;
+}
+
+int dnp_patch_pca_f32(const float* pts, int64_t ld_pts, const int64_t* patch_off, const int64_t* patch_idx,
+                      int64_t P, double* mean, double* evals, double* evecs, void* stream) {
+    const int rc = patch_pca_check(pts, ld_pts, patch_off, P, mean, evals, evecs);
+    if (rc != DNP_OK) return rc > 0 ? DNP_OK : rc;
+    hipLaunchKernelGGL((patch_pca_kernel<float>), dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pts, ld_pts,
+                       patch_off, patch_idx, mean, evals, evecs);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+int dnp_patch_pca_f64(const double* pts, int64_t ld_pts, const int64_t* patch_off, const int64_t* patch_idx,
+                      int64_t P, double* mean, double* evals, double* evecs, void* stream) {
+    const int rc = patch_pca_check(pts, ld_pts, patch_off, P, mean, evals, evecs);
+    if (rc != DNP_OK) return rc > 0 ? DNP_OK : rc;
+    hipLaunchKernelGGL((patch_pca_kernel<double>), dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pts, ld_pts,
+                       patch_off, patch_idx, mean, evals, evecs);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+int dnp_patch_greedy_max_patches(void) { return 64 * 64; }
+
+int dnp_patch_greedy(const double* W, int64_t P, const int64_t* start, int64_t* order, double* sigma,
+                     double* chosen, void* stream) {
+    clear_error();
+    DNP_REQUIRE(P >= 0, "negative P");
+    if (P == 0) return DNP_OK;
+    DNP_REQUIRE(W && start && order && sigma, "NULL pointer");
+    DNP_REQUIRE(P == 1 || chosen, "NULL chosen");
+    DNP_REQUIRE(P <= dnp_patch_greedy_max_patches(), "P=%lld exceeds the %d patches of the device greedy loop",
+                (long long)P, dnp_patch_greedy_max_patches());
+    const hipStream_t st = (hipStream_t)stream;
+#define DNP_LAUNCH_PG(E) \
+    hipLaunchKernelGGL((patch_greedy_kernel<E>), dim3(1), dim3(64), 0, st, W, (int)P, start, order, sigma, chosen)
+    if (P <= 64 * 4) DNP_LAUNCH_PG(4);
+    else if (P <= 64 * 8) DNP_LAUNCH_PG(8);
+    else if (P <= 64 * 16) DNP_LAUNCH_PG(16);
+    else if (P <= 64 * 32) DNP_LAUNCH_PG(32);
+    else DNP_LAUNCH_PG(64);
+#undef DNP_LAUNCH_PG
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+int dnp_combine_signed_f32(const float* dE, int64_t K, int64_t N, const double* sigma, int64_t P, int64_t p_lo,
+                           double* E, int accumulate, void* stream) {
+    clear_error();
+    DNP_REQUIRE(K >= 0 && N >= 0 && P >= 0, "negative size");
+    DNP_REQUIRE(p_lo >= 0 && p_lo + K <= P, "slabs [%lld,%lld) outside the %lld patches", (long long)p_lo,
+                (long long)(p_lo + K), (long long)P);
+    if (N == 0) return DNP_OK;
+    DNP_REQUIRE(E, "NULL E");
+    DNP_REQUIRE(K == 0 || (dE && sigma), "NULL pointer");
+    const int64_t N3 = N * 3;
+    hipLaunchKernelGGL(combine_signed_kernel, dim3((unsigned)ceil_div(N3, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dE, K, N3, sigma ? sigma + p_lo : nullptr, E, accumulate);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+// ---- host: merge of small voxel cells ---------------------------------------------------------------------------
+int dnp_merge_cells(const int32_t* cell_ijk, const int64_t* cell_size, int64_t C, int64_t min_patch,
+                    int64_t* seq, int64_t* seq_off, int64_t* n_out, int32_t* sweeps_out) {
+    clear_error();
+    DNP_REQUIRE(C >= 0, "negative C");
+    DNP_REQUIRE(seq_off && n_out, "NULL output pointer");
+    DNP_REQUIRE(C == 0 || (cell_ijk && cell_size && seq), "NULL pointer");
+    // voxel -> live cell that currently contains it.  Keys are packed 21 bits per axis (shifted by +1 so that the
+    // -1 neighbours of index 0 stay non-negative).
+    auto key = [](int64_t i, int64_t j, int64_t k) { return ((i + 1) << 42) | ((j + 1) << 21) | (k + 1); };
+    std::unordered_map<int64_t, int32_t> owner;
+    owner.reserve((size_t)C * 2);
+    std::vector<std::vector<int32_t>> members((size_t)C);     // original cells of a live cell, concatenation order
+    std::vector<int64_t> size((size_t)C);
+    for (int64_t c = 0; c < C; ++c) {
+        const int32_t* v = cell_ijk + c * 3;
+        DNP_REQUIRE(v[0] >= 0 && v[1] >= 0 && v[2] >= 0 && v[0] < (1 << 20) && v[1] < (1 << 20) && v[2] < (1 << 20),
+                    "cell %lld has a coordinate outside [0, 2^20)", (long long)c);
+        owner[key(v[0], v[1], v[2])] = (int32_t)c;
+        members[(size_t)c].push_back((int32_t)c);
+        size[(size_t)c] = cell_size[c];
+    }
+    int sweeps = 0;
+    bool again = true;
+    while (again && sweeps < 10) {                           // max_recursive_merges = 10
+        again = false;
+        ++sweeps;
+        for (int64_t i = 0; i < C; ++i) {
+            auto& mine = members[(size_t)i];
+            if (mine.empty() || size[(size_t)i] >= min_patch) continue;
+            // find_dij: the LAST (highest index) other live cell with a voxel in the 26-neighbourhood of one of ours
+            int32_t target = -1;
+            for (int32_t c : mine) {
+                const int32_t* v = cell_ijk + (int64_t)c * 3;
+                for (int di = -1; di <= 1; ++di)
+                    for (int dj = -1; dj <= 1; ++dj)
+                        for (int dk = -1; dk <= 1; ++dk) {
+                            auto it = owner.find(key(v[0] + di, v[1] + dj, v[2] + dk));
+                            if (it != owner.end() && it->second != (int32_t)i && it->second > target) target = it->second;
+                        }
+            }
+            if (target < 0) continue;
+            auto& theirs = members[(size_t)target];
+            for (int32_t c : mine) {
+                const int32_t* v = cell_ijk + (int64_t)c * 3;
+                owner[key(v[0], v[1], v[2])] = target;
+                theirs.push_back(c);
+            }
+            size[(size_t)target] += size[(size_t)i];
+            size[(size_t)i] = 0;
+            mine.clear();
+            if (size[(size_t)target] < min_patch) again = true;
+        }
+    }
+    int64_t n = 0, pos = 0;
+    seq_off[0] = 0;
+    for (int64_t i = 0; i < C; ++i) {
+        if (members[(size_t)i].empty() || size[(size_t)i] < min_patch) continue;
+        for (int32_t c : members[(size_t)i]) seq[pos++] = c;
+        seq_off[++n] = pos;
+    }
+    *n_out = n;
+    if (sweeps_out) *sweeps_out = sweeps;
+    return DNP_OK;
+}
+
+}  // extern "C"

@@ -69,6 +69,8 @@ struct PairArgs {
     int64_t ld_out;
     int out_scatter;         // row = tgt_idx[t]
     int accumulate;          // out += result
+    int* nonfinite;          // [2] counters of inf / nan leaf components zeroed (direct epilogue), or nullptr
+    F far_d2;                // FAR kernels: squared box distance beyond which the one-transcendental chain is used
     int32_t chunk_off[kMaxChunks + 1];  // by-value CSR offsets when chunk_off_dev == nullptr
 };
 
@@ -137,6 +139,48 @@ __device__ __forceinline__ void pair_field(F sx, F sy, F sz, F px, F py, F pz, F
     bz = M::fma(w, pz, bz);
 }
 
+// Far-field chain (eps > 0, every pair of the wave farther apart than far_d2 = (eps / kFarRatio)^(2/3), i.e.
+// e = eps / |r|^3 < kFarRatio): ONE transcendental instead of two.
+//   u = rsq(d2); u3 = u^3 = 1/|r|^3;  w = 1/(|r|^3 + eps) = u3 / (1 + e) = u3 (1 - e + e^2 - ...),  e = eps u3
+// truncated after e^2: relative error e^3 < kFarRatio^3 = 8e-9, an eighth of an fp32 ulp.  22 full-rate + 1
+// quarter-rate instructions against 19 + 2 for the exact chain (a transcendental costs ~13 issue cycles when
+// mixed with FMAs).  No coincident pair can be in a far tile.
+constexpr double kFarRatio = 2e-3;
+
+template <typename F>
+__device__ __forceinline__ void pair_field_far(F sx, F sy, F sz, F px, F py, F pz, F tx, F ty, F tz, F eps,
+                                               F& ax, F& ay, F& az, F& bx, F& by, F& bz) {
+    using M = Math<F>;
+    const F rx = sx - tx, ry = sy - ty, rz = sz - tz;
+    const F d2 = M::fma(rz, rz, M::fma(ry, ry, rx * rx));
+    const F pr = M::fma(pz, rz, M::fma(py, ry, px * rx));
+    const F u = M::rsq(d2);
+    const F u2 = u * u;
+    const F u3 = u2 * u;
+    const F e = eps * u3;
+    const F w = M::fma(u3, M::fma(e, e, -e), u3);
+    const F a = pr * (w * u2);
+    ax = M::fma(a, rx, ax);
+    ay = M::fma(a, ry, ay);
+    az = M::fma(a, rz, az);
+    bx = M::fma(w, px, bx);
+    by = M::fma(w, py, by);
+    bz = M::fma(w, pz, bz);
+}
+
+template <typename F>
+__device__ __forceinline__ F wave_min(F v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const F o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
+    return v;
+}
+template <typename F>
+__device__ __forceinline__ F wave_max(F v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const F o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    return v;
+}
+
 template <typename F>
 __device__ __forceinline__ void pair_potential(F sx, F sy, F sz, F px, F py, F pz, F tx, F ty, F tz, F& phi) {
     using M = Math<F>;
@@ -150,11 +194,17 @@ __device__ __forceinline__ void pair_potential(F sx, F sy, F sz, F px, F py, F p
 // LDS image of one staged source row: two 16-byte slots, (x,y,z,px) and (py,pz,-,-).
 template <typename F> struct Vec4 { F x, y, z, w; };
 
-template <typename F, typename PT, int MODE, int KT, int V>
+// FAR (field mode, kFast only): a wave whose targets' bounding box is farther than sqrt(far_d2) from the bounding
+// box of the current 256-source tile runs the tile through pair_field_far.  The test is wave-uniform (boxes, not
+// pairs), so there is no divergence and no per-pair compare; it pays when sources and targets are spatially
+// coherent runs - the patch-sorted clouds of the drivers.
+template <typename F, typename PT, int MODE, int KT, int V, bool FAR = false>
 __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
     using M = Math<F>;
     constexpr int NC = (MODE == kField) ? 3 : 1;
+    constexpr bool kFarPath = FAR && MODE == kField && V == kFast;
     __shared__ __attribute__((aligned(16))) Vec4<F> lds[2][kBlock][2];
+    __shared__ F tile_box[2][kBlock / 64][6];      // per staged tile and staging wave: min xyz, max xyz
 
     const int tid = threadIdx.x;
     const int64_t chunk = blockIdx.y;
@@ -184,6 +234,21 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
         }
     }
 
+    // bounding box of this wave's targets (wave-uniform)
+    F tlo[3] = {F(0), F(0), F(0)}, thi[3] = {F(0), F(0), F(0)};
+    if (kFarPath) {
+        F lo[3] = {M::kHuge, M::kHuge, M::kHuge}, hi[3] = {-M::kHuge, -M::kHuge, -M::kHuge};
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+            if (trow[k] >= 0) {
+                lo[0] = tx[k] < lo[0] ? tx[k] : lo[0]; hi[0] = tx[k] > hi[0] ? tx[k] : hi[0];
+                lo[1] = ty[k] < lo[1] ? ty[k] : lo[1]; hi[1] = ty[k] > hi[1] ? ty[k] : hi[1];
+                lo[2] = tz[k] < lo[2] ? tz[k] : lo[2]; hi[2] = tz[k] > hi[2] ? tz[k] : hi[2];
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { tlo[c] = wave_min<F>(lo[c]); thi[c] = wave_max<F>(hi[c]); }
+    }
+
     double acc[KT][NC];
 #pragma unroll
     for (int k = 0; k < KT; ++k)
@@ -192,8 +257,10 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
 
     // ---- staging helpers -------------------------------------------------------------------
     F g0, g1, g2, g3, g4, g5;
+    bool g_real = false;
     auto load_row = [&](int64_t s) {
-        if (s < s_end) {
+        g_real = s < s_end;
+        if (g_real) {
             const int64_t row = a.src_idx ? a.src_idx[s] : s;
             const F* p = a.src + row * a.ld_src;
             g0 = p[0]; g1 = p[1]; g2 = p[2]; g3 = p[3]; g4 = p[4]; g5 = p[5];
@@ -204,6 +271,16 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
     auto store_row = [&](int buf) {
         lds[buf][tid][0] = Vec4<F>{g0, g1, g2, g3};
         lds[buf][tid][1] = Vec4<F>{g4, g5, F(0), F(0)};
+        if (kFarPath) {    // this wave's 64 staged rows -> their box (padding rows excluded)
+            const F l0 = wave_min<F>(g_real ? g0 : M::kHuge), l1 = wave_min<F>(g_real ? g1 : M::kHuge),
+                    l2 = wave_min<F>(g_real ? g2 : M::kHuge);
+            const F h0 = wave_max<F>(g_real ? g0 : -M::kHuge), h1 = wave_max<F>(g_real ? g1 : -M::kHuge),
+                    h2 = wave_max<F>(g_real ? g2 : -M::kHuge);
+            if ((tid & 63) == 0) {
+                F* b = tile_box[buf][tid >> 6];
+                b[0] = l0; b[1] = l1; b[2] = l2; b[3] = h0; b[4] = h1; b[5] = h2;
+            }
+        }
     };
 
     const int64_t n_src = s_end - s_begin;
@@ -221,6 +298,26 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
         int n_here = (int)((s_end - tile_s) < kBlock ? (s_end - tile_s) : kBlock);
         n_here = (n_here + 3) & ~3;                                // rows past s_end are padding rows (kUnroll | 4)
 
+        bool far_tile = false;
+        if (kFarPath) {
+            F d2box = F(0);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                F slo = tile_box[buf][0][c], shi = tile_box[buf][0][3 + c];
+#pragma unroll
+                for (int w = 1; w < kBlock / 64; ++w) {
+                    const F l = tile_box[buf][w][c], h = tile_box[buf][w][3 + c];
+                    slo = l < slo ? l : slo; shi = h > shi ? h : shi;
+                }
+                F gap = slo - thi[c];
+                const F gap2 = tlo[c] - shi;
+                gap = gap2 > gap ? gap2 : gap;
+                gap = gap > F(0) ? gap : F(0);
+                d2box = M::fma(gap, gap, d2box);
+            }
+            far_tile = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2)) != 0;
+        }
+
         for (int j0 = 0; j0 < n_here; j0 += kFlush) {
             const int j1 = (j0 + kFlush < n_here) ? j0 + kFlush : n_here;   // multiples of kSets
             if (MODE == kField) {
@@ -233,17 +330,33 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
                     for (int k = 0; k < KT; ++k)
 #pragma unroll
                         for (int c = 0; c < 3; ++c) A[u][k][c] = B[u][k][c] = F(0);
-                for (int j = j0; j < j1; j += kUnroll) {
+                if (kFarPath && far_tile) {
+                    for (int j = j0; j < j1; j += kUnroll) {
 #pragma unroll
-                    for (int u = 0; u < kUnroll; ++u) {
-                        const Vec4<F> s0 = lds[buf][j + u][0];
-                        const Vec4<F> s1 = lds[buf][j + u][1];
-                        constexpr int kS = kSets;
+                        for (int u = 0; u < kUnroll; ++u) {
+                            const Vec4<F> s0 = lds[buf][j + u][0];
+                            const Vec4<F> s1 = lds[buf][j + u][1];
+                            constexpr int kS = kSets;
 #pragma unroll
-                        for (int k = 0; k < KT; ++k)
-                            pair_field<F, V>(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx[k], ty[k], tz[k], a.eps,
-                                             A[u % kS][k][0], A[u % kS][k][1], A[u % kS][k][2], B[u % kS][k][0],
-                                             B[u % kS][k][1], B[u % kS][k][2]);
+                            for (int k = 0; k < KT; ++k)
+                                pair_field_far<F>(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx[k], ty[k], tz[k], a.eps,
+                                                  A[u % kS][k][0], A[u % kS][k][1], A[u % kS][k][2], B[u % kS][k][0],
+                                                  B[u % kS][k][1], B[u % kS][k][2]);
+                        }
+                    }
+                } else {
+                    for (int j = j0; j < j1; j += kUnroll) {
+#pragma unroll
+                        for (int u = 0; u < kUnroll; ++u) {
+                            const Vec4<F> s0 = lds[buf][j + u][0];
+                            const Vec4<F> s1 = lds[buf][j + u][1];
+                            constexpr int kS = kSets;
+#pragma unroll
+                            for (int k = 0; k < KT; ++k)
+                                pair_field<F, V>(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx[k], ty[k], tz[k], a.eps,
+                                                 A[u % kS][k][0], A[u % kS][k][1], A[u % kS][k][2], B[u % kS][k][0],
+                                                 B[u % kS][k][1], B[u % kS][k][2]);
+                        }
                     }
                 }
 #pragma unroll
@@ -296,15 +409,21 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     F v = (F)((MODE == kField) ? -acc[k][c] : acc[k][c]);
-                    if (!__builtin_isfinite(v)) v = F(0);            // field_utils.py:110-115 / :53-54
+                    if (!__builtin_isfinite(v)) {                    // field_utils.py:110-115 / :53-54
+                        if (a.nonfinite) atomicAdd(a.nonfinite + (v != v ? 1 : 0), 1);
+                        v = F(0);
+                    }
                     o[c] = a.accumulate ? (F)(o[c] + v) : v;
                 }
             } else {
                 PT* o = a.partial + ((int64_t)chunk * a.T + t) * NC;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const double v = (MODE == kField) ? -acc[k][c] : acc[k][c];
-                    o[c] = excluded ? PT(0) : (PT)v;
+                    PT v = (PT)((MODE == kField) ? -acc[k][c] : acc[k][c]);
+                    // patch mode: a slab is the complete dE of one field_grad call (one leaf), so the reference's
+                    // Inf/NaN zeroing (field_utils.py:114-115) applies here; otherwise reduce_kernel applies it
+                    if (a.tgt_group && !__builtin_isfinite(v)) v = PT(0);
+                    o[c] = excluded ? PT(0) : v;
                 }
             }
         }

@@ -28,7 +28,7 @@ __all__ = [
     "self_interaction_all", "random_self_interaction", "reference_field",
     "strongest_field_propagation_reps", "strongest_field_propagation",
     "strongest_field_propagation_points", "xie_field", "xie_intersaction", "xie_distance",
-    "xie_propagation_points_in_order", "torch", "np", "util",
+    "xie_propagation_points_in_order", "last_trace", "torch", "np", "util",
 ]
 
 # "auto": batched (all per-patch fields in one launch, greedy loop as P x P host arithmetic) when the
@@ -105,7 +105,8 @@ def _idx(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
     return t.to(device=dev, dtype=torch.int64).contiguous()
 
 
-def _pairs_into(kind: str, src, src_idx, tgt, tgt_idx, eps, max_pts, out, out_scatter=False, accumulate=False):
+def _pairs_into(kind: str, src, src_idx, tgt, tgt_idx, eps, max_pts, out, out_scatter=False, accumulate=False,
+                nonfinite=None):
     """Launch K1/K2 on staged device tensors.  src/tgt/out live on the compute device."""
     lib = _lib.require_device()
     S = src.shape[0] if src_idx is None else src_idx.shape[0]
@@ -122,13 +123,90 @@ def _pairs_into(kind: str, src, src_idx, tgt, tgt_idx, eps, max_pts, out, out_sc
             fn = lib.dnp_field_grad_f64 if f64 else lib.dnp_field_grad_f32
             rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(src_idx), _lib.ptr(tgt), T, _ld(tgt), _lib.ptr(tgt_idx),
                     float(eps), int(max_pts), _lib.ptr(out), out.stride(0) if out.shape[0] > 1 else 3,
-                    int(bool(out_scatter)), int(bool(accumulate)), _lib.ptr(ws), ws.numel(), stream)
+                    int(bool(out_scatter)), int(bool(accumulate)), _lib.ptr(nonfinite), _lib.ptr(ws), ws.numel(),
+                    stream)
         else:
             fn = lib.dnp_potential_f64 if f64 else lib.dnp_potential_f32
             rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(src_idx), _lib.ptr(tgt), T, _ld(tgt), _lib.ptr(tgt_idx),
                     int(max_pts), _lib.ptr(out), 1, _lib.ptr(ws), nbytes, stream)
     _lib.check(rc)
     return out
+
+
+# ---- the reference's "warning: %d inf in field_grad" prints (field_utils.py:110-113) -----------------------------
+# The kernels count the Inf / NaN leaf components they zero; the two counters of a call travel to pinned host
+# memory with an asynchronous copy, and the line is printed as soon as the copy has landed - at the latest by the
+# next call on this thread, by flush_warnings() or at interpreter exit - so that a field_grad call never waits
+# for the device just to find out that there is nothing to warn about.
+_WARN_RING = 64
+
+
+class _WarnState:
+    def __init__(self, dev):
+        self.dev = dev
+        self.ring = torch.zeros((_WARN_RING, 2), dtype=torch.int32, device=dev)
+        self.host = torch.zeros((_WARN_RING, 2), dtype=torch.int32).pin_memory()
+        self.slot = 0
+        self.pending = []          # (event, slot)
+
+    def next_slot(self):
+        if self.slot == _WARN_RING:             # every slot has been used once: drain, then start over
+            self.drain(block=True)
+            self.ring.zero_()
+            self.slot = 0
+        i = self.slot
+        self.slot += 1
+        return i
+
+    def submit(self, i):
+        self.host[i].copy_(self.ring[i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        self.pending.append((ev, i))
+
+    def drain(self, block=False):
+        keep = []
+        for ev, i in self.pending:
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                keep.append((ev, i))
+                continue
+            n_inf, n_nan = int(self.host[i, 0]), int(self.host[i, 1])
+            if n_inf:
+                print("warning: %d inf in field_grad" % n_inf)
+            if n_nan:
+                print("warning: %d nan in field_grad" % n_nan)
+        self.pending = keep
+
+
+_warn_states = []
+_warn_lock = threading.Lock()
+
+
+def _warn_state(dev) -> _WarnState:
+    states = getattr(_tls, "warn", None)
+    if states is None:
+        states = _tls.warn = {}
+    st = states.get(dev.index)
+    if st is None:
+        st = states[dev.index] = _WarnState(dev)
+        with _warn_lock:
+            _warn_states.append(st)
+    return st
+
+
+def flush_warnings() -> None:
+    """Print every pending Inf/NaN warning of field_grad calls made so far (waits for the device)."""
+    with _warn_lock:
+        states = list(_warn_states)
+    for st in states:
+        st.drain(block=True)
+
+
+import atexit  # noqa: E402
+
+atexit.register(lambda: flush_warnings() if _warn_states else None)
 
 
 def _field_like(kind, sources, means, eps, recursive, max_pts):
@@ -145,11 +223,15 @@ def _field_like(kind, sources, means, eps, recursive, max_pts):
     T = tgt.shape[0]
     out = torch.empty((T, 3) if kind == "field" else (T,), dtype=wd, device=dev)
     if T > 0:
-        _pairs_into(kind, src, None, tgt, None, eps, max_pts if recursive else 0, out)
-    if kind == "field":
-        # the reference prints (never raises) when a leaf produced Inf/NaN; the kernel has already
-        # zeroed them, so there is nothing left to warn about here.
-        pass
+        if kind == "field":
+            # the reference prints (never raises) when a leaf produced Inf/NaN, then zeroes them
+            st = _warn_state(dev)
+            st.drain()
+            slot = st.next_slot()
+            _pairs_into(kind, src, None, tgt, None, eps, max_pts if recursive else 0, out, nonfinite=st.ring[slot])
+            st.submit(slot)
+        else:
+            _pairs_into(kind, src, None, tgt, None, eps, max_pts if recursive else 0, out)
     return out.to(device=in_dev, dtype=in_dtype) if (out.device != in_dev or out.dtype != in_dtype) else out
 
 
@@ -251,36 +333,78 @@ def reference_field(pc1, pc2):
 
 
 # ---------------------------------------------------------------------------------------------------
+# traces
+# ---------------------------------------------------------------------------------------------------
+def _set_trace(kind: str, **items) -> None:
+    """Remember the visit order / flips / chosen interactions of the calling THREAD's last driver call.
+    Thread-local: the reference runs these drivers concurrently from Python threads (util.py:187-196,
+    :308-327).  Values may be device tensors; they are converted when somebody asks (last_trace)."""
+    store = getattr(_tls, "traces", None)
+    if store is None:
+        store = _tls.traces = {}
+    store[kind] = items
+
+
+def last_trace(kind: str) -> dict:
+    """Trace of this thread's last call of a greedy driver as numpy arrays.  kind: "patches"
+    (strongest_field_propagation), "reps" (..._reps), "points" (..._points), "sharded"
+    (parallel.sharded_patch_propagation).  Keys: order, sigma (+-1 per patch), chosen, start."""
+    items = getattr(_tls, "traces", {}).get(kind)
+    if items is None:
+        raise KeyError(f"no {kind!r} driver has run on this thread")
+    out = {}
+    for k, v in items.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+            if v.ndim == 1 and v.shape[0] == 1 and k == "start":
+                v = int(v[0])
+        out[k] = v
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
 # greedy patch drivers
 # ---------------------------------------------------------------------------------------------------
-def _flattest_patch(pts: torch.Tensor, patches: List[torch.Tensor]) -> int:
-    """argmin_k |lambda_min(cov(patch k))| (field_utils.py:303-306 / :230-233, util.pca_eigen_values per
-    patch in the reference).  All P covariances are formed with two segmented sums and handed to ONE batched
-    eigvalsh instead of P separate eigh calls (43 ms -> <1 ms at P = 256); same formula
-    cov = (x - mean)^T (x - mean) / n in fp32, different summation order (see DESIGN.md on the start patch)."""
-    dev = pts.device
-    P = len(patches)
-    off, idx = _csr(patches, dev)
-    sizes = (off[1:] - off[:-1])
-    pid = torch.repeat_interleave(torch.arange(P, device=dev), sizes)
-    xyz = pts[idx, :3]
-    cnt = sizes.to(xyz.dtype).clamp(min=1)[:, None]
-    mean = torch.zeros((P, 3), dtype=xyz.dtype, device=dev).index_add_(0, pid, xyz) / cnt
-    rel = xyz - mean[pid]
-    outer = (rel[:, :, None] * rel[:, None, :]).reshape(-1, 9)
-    cov = (torch.zeros((P, 9), dtype=xyz.dtype, device=dev).index_add_(0, pid, outer) / cnt).reshape(P, 3, 3)
-    lam = torch.linalg.eigvalsh(cov.cpu())[:, 0]
-    return int(torch.argmin(lam.abs()))
+def _flattest_patch(pts: torch.Tensor, patches) -> torch.Tensor:
+    """argmin_k |lambda_min(cov(patch k))| (field_utils.py:303-306 / :230-233; util.pca_eigen_values per patch
+    in the reference) as a 1-element int64 tensor on pts' device - no host round trip.  The covariances come
+    from util.patch_pca (fp64, deterministic), the one shared implementation: among near-planar patches the
+    reference's own fp32 choice is decided by BLAS rounding; fp64 picks the patch that is actually flattest,
+    which is the reference's choice on every golden cloud (G6, G7, G13, G15)."""
+    _, evals, _, _ = util.patch_pca(pts, patches)
+    return torch.argmin(evals[:, 0].abs()).reshape(1)
 
 
-def _flip_lists(work: torch.Tensor, index_lists) -> None:
-    """work[idx, 3:] *= -1 for every list (each point once per listing, as the reference's loop)."""
-    lists = [p for p in index_lists if p.numel()]
-    if lists:
-        allidx = torch.cat(lists)
-        cnt = torch.bincount(allidx, minlength=work.shape[0])
-        odd = (cnt % 2 == 1)
-        work[odd, 3:] = -work[odd, 3:]
+def _start_tensor(work, patches, start_patch) -> torch.Tensor:
+    if start_patch is None:
+        return _flattest_patch(work, patches)
+    if isinstance(start_patch, torch.Tensor):
+        return start_patch.to(device=work.device, dtype=torch.int64).reshape(1)
+    return torch.tensor([int(start_patch)], dtype=torch.int64, device=work.device)
+
+
+def _point_patch_ids(idx: torch.Tensor, sizes: np.ndarray, n: int) -> torch.Tensor:
+    """patch id of every point (-1 = in no patch) from the CSR form of disjoint patches."""
+    dev = idx.device
+    point_patch = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    if idx.numel():
+        point_patch[idx] = torch.repeat_interleave(torch.arange(len(sizes), device=dev),
+                                                   torch.from_numpy(sizes).to(dev), output_size=int(idx.numel()))
+    return point_patch
+
+
+def _flip_by_listing(work: torch.Tensor, neg: torch.Tensor, lists_csr) -> None:
+    """work[idx, 3:] *= -1 once per listing of a point in a patch k with neg[k] (the reference's loop flips a
+    point every time it is listed): parity of the listing count, all on the device."""
+    off, idx, sizes = lists_csr
+    if idx.numel() == 0:
+        return
+    pid = torch.repeat_interleave(torch.arange(len(sizes), device=idx.device), torch.from_numpy(sizes).to(idx.device),
+                                  output_size=int(idx.numel()))
+    cnt = torch.zeros(work.shape[0], dtype=torch.int32, device=work.device)
+    cnt.index_add_(0, idx, neg[pid].to(torch.int32))
+    s = (1 - 2 * (cnt % 2)).to(work.dtype)
+    work[:, 3:] = work[:, 3:] * s[:, None]
 
 
 def _diffuse_sign_pass(work: torch.Tensor, E: torch.Tensor, index_lists) -> None:
@@ -289,16 +413,18 @@ def _diffuse_sign_pass(work: torch.Tensor, E: torch.Tensor, index_lists) -> None
     after the first visit E.n > 0, so the second visit multiplies by +1."""
     if len(index_lists) == 0:
         return
-    sel = torch.unique(torch.cat([p.to(work.device) for p in index_lists]))
-    s = ((E[sel] * work[sel, 3:]).sum(dim=-1) > 0).to(work.dtype) * 2 - 1
-    work[sel, 3:] = work[sel, 3:] * s[:, None]
+    listed = torch.zeros(work.shape[0], dtype=torch.bool, device=work.device)
+    if isinstance(index_lists, util.PatchList):
+        listed[index_lists.flat.to(work.device)] = True
+    else:
+        listed[torch.cat([p.to(work.device) for p in index_lists])] = True
+    pos = (E * work[:, 3:]).sum(dim=-1) > 0
+    s = torch.where(listed & ~pos, -1.0, 1.0).to(work.dtype)
+    work[:, 3:] = work[:, 3:] * s[:, None]
 
 
 def _csr(patches: List[torch.Tensor], dev) -> Tuple[torch.Tensor, torch.Tensor]:
-    sizes = [int(p.shape[0]) for p in patches]
-    off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64, device=dev)
-    idx = torch.cat([p.to(device=dev, dtype=torch.int64) for p in patches]) if patches else \
-        torch.zeros(0, dtype=torch.int64, device=dev)
+    off, idx, _ = util.patch_csr(patches, dev)
     return off, idx
 
 
@@ -312,7 +438,7 @@ def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, ep
     lib = _lib.require_device()
     N = work.shape[0]
     dE = torch.empty((p1 - p0, N, 3), dtype=torch.float32, device=work.device)
-    with torch.cuda.device(work.device):
+    with _on_device(work.device):
         rc = lib.dnp_patch_fields_f32(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
                                       off.shape[0] - 1, _lib.ptr(point_patch), p0, p1, float(eps), _lib.ptr(dE),
                                       _lib.current_stream())
@@ -325,7 +451,7 @@ def _interaction_rows(dE, work, off, idx) -> torch.Tensor:
     K, N = dE.shape[0], dE.shape[1]
     P = off.shape[0] - 1
     W = torch.empty((K, P), dtype=torch.float64, device=work.device)
-    with torch.cuda.device(work.device):
+    with _on_device(work.device):
         rc = lib.dnp_interactions_f32(_lib.ptr(dE), K, N, _lib.ptr(work), work.stride(0), _lib.ptr(off),
                                       _lib.ptr(idx), P, _lib.ptr(W), _lib.current_stream())
     _lib.check(rc)
@@ -333,16 +459,28 @@ def _interaction_rows(dE, work, off, idx) -> torch.Tensor:
 
 
 def _combine(dE, coef: torch.Tensor, slab: torch.Tensor, E: torch.Tensor, accumulate: bool):
+    """E (+)= sum_i coef_i dE[slab_i] as a sequential fp32 chain in the order given (dnp_combine_fields_f32)."""
     lib = _lib.require_device()
     K, N = dE.shape[0], dE.shape[1]
-    with torch.cuda.device(E.device):
+    with _on_device(E.device):
         rc = lib.dnp_combine_fields_f32(_lib.ptr(dE), K, N, _lib.ptr(coef), _lib.ptr(slab), coef.shape[0],
                                         _lib.ptr(E), int(accumulate), _lib.current_stream())
     _lib.check(rc)
 
 
+def _combine_signed(dE, sigma: torch.Tensor, p_lo: int, E64: torch.Tensor, accumulate: bool):
+    """E64 (+)= sum_k sigma[p_lo + k] dE[k], accumulated in fp64 (dnp_combine_signed_f32)."""
+    lib = _lib.require_device()
+    K, N = dE.shape[0], dE.shape[1]
+    with _on_device(E64.device):
+        rc = lib.dnp_combine_signed_f32(_lib.ptr(dE), K, N, _lib.ptr(sigma), sigma.shape[0], int(p_lo), _lib.ptr(E64),
+                                        int(accumulate), _lib.current_stream())
+    _lib.check(rc)
+
+
 def greedy_order_from_interactions(W: np.ndarray, start: int):
-    """The greedy loop of field_utils.py:314-324 / :242-254 on the P x P interaction matrix:
+    """The greedy loop of field_utils.py:314-324 / :242-254 on the P x P interaction matrix (host form; the
+    drivers run the same loop on the device, dnp_patch_greedy):
     I_j = sum_{k visited} sigma_k W[k, j]; pick argmax |I_j| over the remaining patches (first
     maximum in patch order, as torch.argmax over the `remaining` list), flip when I_j < 0.
     Returns (order[P], sigma[P], chosen_interaction[P-1])."""
@@ -365,33 +503,52 @@ def greedy_order_from_interactions(W: np.ndarray, start: int):
     return np.array(order), sigma, np.array(chosen)
 
 
-def _batched_patch_propagation(work: torch.Tensor, patches: List[torch.Tensor], start: int, diffuse: bool,
-                               eps: float = 1e-5, want_E: bool = True, shard=None):
-    """Core of the batched drivers on a device cloud `work[N,6]` (normals already weight-scaled).
+def _greedy_on_device(W: torch.Tensor, start_t: torch.Tensor):
+    """(order[P] int64, sigma[P] fp64, chosen[P-1] fp64) device tensors from the full W[P,P] (fp64, device)."""
+    lib = _lib.require_device()
+    P = W.shape[0]
+    dev = W.device
+    if P > lib.dnp_patch_greedy_max_patches():
+        order, sigma, chosen = greedy_order_from_interactions(W.cpu().numpy(), int(start_t.item()))
+        return (torch.from_numpy(order).to(dev), torch.from_numpy(sigma).to(dev), torch.from_numpy(chosen).to(dev))
+    order = torch.empty(P, dtype=torch.int64, device=dev)
+    sigma = torch.empty(P, dtype=torch.float64, device=dev)
+    chosen = torch.empty(max(P - 1, 0), dtype=torch.float64, device=dev)
+    Wc = W if W.is_contiguous() else W.contiguous()
+    with _on_device(dev):
+        rc = lib.dnp_patch_greedy(_lib.ptr(Wc), P, _lib.ptr(start_t), _lib.ptr(order), _lib.ptr(sigma),
+                                  _lib.ptr(chosen), _lib.current_stream())
+    _lib.check(rc)
+    return order, sigma, chosen
 
-    Returns (order, sigma, chosen, E, point_patch): E[N,3] is this rank's part of the accumulated field of
-    the diffuse form in the caller's point order (None unless want_E and diffuse), point_patch[N] the patch
-    id per point (-1 = in no patch).  `shard` = (rank, world, gather_fn): patches are split over ranks in
-    contiguous size-balanced blocks, each rank computes its slabs and W rows, gather_fn(rows, bounds)
-    returns the full W on every rank."""
+
+def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tensor, diffuse: bool,
+                               eps: float = 1e-5, want_E: bool = True, shard=None):
+    """Core of the batched drivers on a device cloud `work[N,6]` (normals already weight-scaled); everything
+    stays on the device - no host synchronisation between the launches.
+
+    Returns (order, sigma, chosen, E64, point_patch): device tensors; E64[N,3] is this rank's part of the
+    accumulated field of the diffuse form (fp64 sum of the sigma-signed fp32 slabs, in the caller's point
+    order; None unless want_E and diffuse), point_patch[N] the patch id per point (-1 = in no patch).
+    `shard` = (rank, world, gather_fn): patches are split over ranks in contiguous size-balanced blocks, each
+    rank computes its slabs and W rows, gather_fn(rows, bounds) returns the full W on every rank."""
     dev = work.device
-    N, P = work.shape[0], len(patches)
-    off, idx = _csr(patches, dev)
-    point_patch = torch.full((N,), -1, dtype=torch.int64, device=dev)
-    sizes = (off[1:] - off[:-1])
-    point_patch[idx] = torch.repeat_interleave(torch.arange(P, device=dev), sizes)
+    N = work.shape[0]
+    off, idx, sizes = util.patch_csr(patches, dev)
+    P = len(sizes)
+    orig_point_patch = _point_patch_ids(idx, sizes, N)
     # data layout for the kernels: the cloud sorted by patch (points in no patch last), so that a patch
     # is a contiguous row range - sources stream linearly and K3 reads its slab rows coalesced
-    orig_work, orig_point_patch = work, point_patch
-    loose = torch.nonzero(point_patch < 0).flatten()
-    perm = torch.cat([idx, loose])
-    work = orig_work[perm].contiguous()
+    if int(sizes.sum()) == N:
+        perm = idx
+    else:
+        perm = torch.cat([idx, torch.nonzero(orig_point_patch < 0).flatten()])
+    swork = work[perm].contiguous()
     point_patch = orig_point_patch[perm].contiguous()
-    idx = None
 
     rank, world, gather = (0, 1, None) if shard is None else shard
     # contiguous blocks of patches per rank, balanced by pair count |patch| * N
-    bounds = _balanced_blocks(sizes.cpu().numpy(), world)
+    bounds = _balanced_blocks(sizes, world)
     p_lo, p_hi = int(bounds[rank]), int(bounds[rank + 1])
 
     per_slab = N * 3 * 4
@@ -400,37 +557,37 @@ def _batched_patch_propagation(work: torch.Tensor, patches: List[torch.Tensor], 
     W_rows, kept = [], None
     for b0 in range(p_lo, p_hi, batch):
         b1 = min(b0 + batch, p_hi)
-        dE = _patch_slabs(work, off, idx, point_patch, b0, b1, eps)
-        W_rows.append(_interaction_rows(dE, work, off, idx))
+        dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps)
+        W_rows.append(_interaction_rows(dE, swork, off, None))
         if keep:
             kept = dE
         else:
             del dE
-    W_local = torch.cat(W_rows, dim=0) if W_rows else torch.zeros((0, P), dtype=torch.float64, device=dev)
+    if len(W_rows) == 1:
+        W_local = W_rows[0]
+    else:
+        W_local = torch.cat(W_rows, dim=0) if W_rows else torch.zeros((0, P), dtype=torch.float64, device=dev)
     W_full = W_local if gather is None else gather(W_local, bounds)
-    order, sigma, chosen = greedy_order_from_interactions(W_full.cpu().numpy(), start)
+    order, sigma, chosen = _greedy_on_device(W_full, start_t)
 
-    E = None
+    E64 = None
     if want_E and diffuse:
-        # E = sum over the visit order of sigma_k dE_k (field_utils.py:330-331), fp32
-        E = torch.zeros((N, 3), dtype=torch.float32, device=dev)
-        mine = [k for k in order if p_lo <= k < p_hi]
-        coef = torch.tensor([sigma[k] for k in mine], dtype=torch.float32, device=dev)
+        # E = sum_k sigma_k dE_k (field_utils.py:330-331).  The reference adds the fp32 slabs one by one in
+        # visit order; here the signed slabs are summed in fp64 and rounded to fp32 once, which is closer to the
+        # exact sum and does not depend on the visit order or on how the patches are split over GPUs.
+        Es = torch.empty((N, 3), dtype=torch.float64, device=dev)
         if keep and kept is not None:
-            slab = torch.tensor([k - p_lo for k in mine], dtype=torch.int64, device=dev)
-            _combine(kept, coef, slab, E, False)
+            _combine_signed(kept, sigma, p_lo, Es, False)
         else:
+            Es.zero_()
             for b0 in range(p_lo, p_hi, batch):
                 b1 = min(b0 + batch, p_hi)
-                dE = _patch_slabs(work, off, idx, point_patch, b0, b1, eps)
-                sel = [k for k in mine if b0 <= k < b1]
-                _combine(dE, torch.tensor([sigma[k] for k in sel], dtype=torch.float32, device=dev),
-                         torch.tensor([k - b0 for k in sel], dtype=torch.int64, device=dev), E, True)
+                dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps)
+                _combine_signed(dE, sigma, b0, Es, True)
                 del dE
-    if E is not None:
-        E_sorted, E = E, torch.empty_like(E)
-        E[perm] = E_sorted
-    return order, sigma, chosen, E, orig_point_patch
+        E64 = torch.empty_like(Es)
+        E64[perm] = Es
+    return order, sigma, chosen, E64, orig_point_patch
 
 
 def _balanced_blocks(sizes: np.ndarray, world: int) -> np.ndarray:
@@ -516,139 +673,149 @@ def _prepare_work(pts: torch.Tensor, weights):
     return work, w
 
 
+def _finish_patch_driver(pts, work, w):
+    if w is not None:
+        work[:, 3:] = work[:, 3:] / w[:, None]
+    pts[:, 3:] = work[:, 3:].to(device=pts.device, dtype=pts.dtype)
+
+
 def strongest_field_propagation(pts, patches, all_patches, diffuse=False, weights=None, start_patch=None):
     """Greedy patch orientation (field_utils.py:286-348).  `pts[N,6]` normals are updated in place.
 
     patches:      list of (i, index tensor) - the filtered patches that receive the per-point
                   diffuse sign pass
     all_patches:  list of index tensors - every patch takes part in the greedy ordering
-    start_patch:  (extension, default None = as the reference) pin the starting patch instead of
-                  choosing the flattest one; the choice among near-planar patches is decided by
-                  fp32 noise in the reference and is not portable across BLAS builds."""
+    start_patch:  (extension, default None = the reference's rule: the flattest patch) pin the starting patch.
+
+    The visit order / flips are available afterwards from last_trace("patches")."""
     with torch.no_grad():
         if len(all_patches) == 0:
             return
         work, w = _prepare_work(pts, weights)
         dev = work.device
-        start = _flattest_patch(work, [p.to(dev) for p in all_patches]) if start_patch is None else int(start_patch)
-        _, idx = _csr(all_patches, dev)
+        start_t = _start_tensor(work, all_patches, start_patch)
         mode = PATCH_MODE
         if mode == "auto":
-            mode = "batched" if _disjoint(idx, work.shape[0]) else "sequential"
+            mode = "batched" if _disjoint(_csr(all_patches, dev)[1], work.shape[0]) else "sequential"
         if mode == "batched":
-            order, sigma, chosen, E, point_patch = _batched_patch_propagation(work, list(all_patches), start, diffuse)
-            sig = torch.tensor(sigma, dtype=torch.float32, device=dev)
-            flip = torch.ones(work.shape[0], dtype=torch.float32, device=dev)
-            inpatch = point_patch >= 0
-            flip[inpatch] = sig[point_patch[inpatch]]
+            order, sigma, chosen, E, point_patch = _batched_patch_propagation(work, all_patches, start_t, diffuse)
+            flip = torch.where(point_patch >= 0, sigma[point_patch.clamp(min=0)], 1.0).to(torch.float32)
             work[:, 3:] = work[:, 3:] * flip[:, None]
         else:
-            order, sigma, chosen, E = _sequential_patch_propagation(work, list(all_patches), start, diffuse)
+            order, sigma, chosen, E = _sequential_patch_propagation(work, list(all_patches), int(start_t.item()),
+                                                                    diffuse)
         if diffuse:
-            _diffuse_sign_pass(work, E, [patch for _, patch in patches])
-        if w is not None:
-            work[:, 3:] = work[:, 3:] / w[:, None]
-        pts[:, 3:] = work[:, 3:].to(device=pts.device, dtype=pts.dtype)
-        strongest_field_propagation.last_trace = dict(order=order, sigma=sigma, chosen=chosen, start=start)
+            _diffuse_sign_pass(work, E.to(torch.float32), [patch for _, patch in patches])
+        _finish_patch_driver(pts, work, w)
+        _set_trace("patches", order=order, sigma=sigma, chosen=chosen, start=start_t)
 
 
 def strongest_field_propagation_reps(input_pc, reps, diffuse=False, weights=None, start_patch=None):
     """Greedy orientation on <=500 representatives per patch (field_utils.py:207-282): `reps` is a
     list of (rep_idx, rest_idx); a flipped patch flips its rest points too; afterwards every
-    non-representative point takes the sign of the field of all representatives (:273-276)."""
+    non-representative point takes the sign of the field of all representatives (:273-276).
+    Trace: last_trace("reps")."""
     input_pc = input_pc.detach()
     with torch.no_grad():
         if len(reps) == 0:
             return
         work, w = _prepare_work(input_pc, weights)
         dev = work.device
-        rep_lists = [r.to(device=dev, dtype=torch.int64) for r, _ in reps]
-        rest_lists = [r.to(device=dev, dtype=torch.int64) for _, r in reps]
-        start = _flattest_patch(work, rep_lists) if start_patch is None else int(start_patch)
-        all_reps = torch.cat(rep_lists)
         N = work.shape[0]
+        rep_csr = util.patch_csr([r for r, _ in reps], dev)
+        rest_csr = util.patch_csr([r for _, r in reps], dev)
+        _, all_reps, rep_sizes = rep_csr
+        rep_lists = util.PatchList(all_reps, rep_sizes)
+        start_t = _start_tensor(work, rep_lists, start_patch)
         mode = PATCH_MODE
         if mode == "auto":
             mode = "batched" if _disjoint(all_reps, N) else "sequential"
+        # the loop's targets are representatives only: run it on the compact sub-cloud of the representatives
+        # (patch k = the contiguous row range of its representatives) and scatter back
+        sub = work[all_reps].contiguous()
+        sub_patches = util.PatchList(torch.arange(all_reps.shape[0], device=dev), rep_sizes)
+        E = torch.zeros((N, 3), dtype=torch.float32, device=dev)
         if mode == "batched":
-            # compact sub-cloud of the representatives: targets of the loop are representatives only
-            sub = work[all_reps].contiguous()
-            sizes = [int(r.shape[0]) for r in rep_lists]
-            offs = np.concatenate([[0], np.cumsum(sizes)])
-            sub_patches = [torch.arange(int(offs[k]), int(offs[k + 1]), device=dev) for k in range(len(reps))]
-            order, sigma, chosen, E_sub, _ = _batched_patch_propagation(sub, sub_patches, start, diffuse)
-            E = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+            order, sigma, chosen, E_sub, _ = _batched_patch_propagation(sub, sub_patches, start_t, diffuse)
             if E_sub is not None:
-                E[all_reps] = E_sub
-            _flip_lists(work, [rep_lists[k] for k in range(len(reps)) if sigma[k] < 0] +
-                        [rest_lists[k] for k in range(len(reps)) if sigma[k] < 0])
+                E[all_reps] = E_sub.to(torch.float32)
+            neg = sigma < 0
         else:
-            # the reps loop restricted to rep targets == patch loop on the rep sub-cloud; run it
-            # sequentially there and scatter back
-            sub = work[all_reps].contiguous()
-            sizes = [int(r.shape[0]) for r in rep_lists]
-            offs = np.concatenate([[0], np.cumsum(sizes)])
-            sub_patches = [torch.arange(int(offs[k]), int(offs[k + 1]), device=dev) for k in range(len(reps))]
-            order, sigma, chosen, E_sub = _sequential_patch_propagation(sub, sub_patches, start, diffuse)
-            E = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+            order, sigma, chosen, E_sub = _sequential_patch_propagation(sub, list(sub_patches), int(start_t.item()),
+                                                                        diffuse)
             E[all_reps] = E_sub
-            _flip_lists(work, [rep_lists[k] for k in range(len(reps)) if sigma[k] < 0] +
-                        [rest_lists[k] for k in range(len(reps)) if sigma[k] < 0])
+            neg = torch.from_numpy(sigma < 0).to(dev)
+        _flip_by_listing(work, neg, rep_csr)
+        _flip_by_listing(work, neg, rest_csr)
         if diffuse:
             _diffuse_sign_pass(work, E, rep_lists)
         # every non-representative point: sign of the field of all representatives
         is_rep = torch.zeros(N, dtype=torch.bool, device=dev)
         is_rep[all_reps] = True
-        rest = torch.arange(N, device=dev)[~is_rep]
-        if rest.numel():
-            src_idx = torch.arange(N, device=dev)[is_rep]
-            E2 = torch.empty((rest.shape[0], 3), dtype=torch.float32, device=dev)
-            _pairs_into("field", work, src_idx, work, rest, 1e-5, 15000, E2)
-            s = ((E2 * work[rest, 3:]).sum(dim=-1) > 0).float() * 2 - 1
-            work[rest, 3:] = work[rest, 3:] * s[:, None]
-        if w is not None:
-            work[:, 3:] = work[:, 3:] / w[:, None]
-        input_pc[:, 3:] = work[:, 3:].to(device=input_pc.device, dtype=input_pc.dtype)
-        strongest_field_propagation_reps.last_trace = dict(order=order, sigma=sigma, chosen=chosen, start=start)
+        if int(rep_sizes.sum()) < N or mode != "batched":
+            rest = torch.nonzero(~is_rep).flatten()
+            if rest.numel():
+                src_idx = torch.nonzero(is_rep).flatten()
+                E2 = torch.empty((rest.shape[0], 3), dtype=torch.float32, device=dev)
+                _pairs_into("field", work, src_idx, work, rest, 1e-5, 15000, E2)
+                s = ((E2 * work[rest, 3:]).sum(dim=-1) > 0).float() * 2 - 1
+                work[rest, 3:] = work[rest, 3:] * s[:, None]
+        _finish_patch_driver(input_pc, work, w)
+        _set_trace("reps", order=order, sigma=sigma, chosen=chosen, start=start_t)
 
 
 def strongest_field_propagation_points(pts: torch.Tensor, diffuse=False, starting_point=0, verbose=False):
     """Per-point greedy orientation (field_utils.py:353-388): N-1 sequential steps of
     `E += field of the chosen point (eps=1e-6)`, `argmax |E.n|` over unvisited points, flip.
-    Runs as one persistent kernel (K4).  Normals are updated in place when pts already lives on
-    the device (the reference's own in-place contract, orient_simple.py:24 relies on it, holds
-    for CPU tensors here as well); returns pts."""
+    Runs as one persistent kernel (K4) in the cloud's own precision: float64 clouds (the reference's socket
+    path, util.py:71-77) are propagated in fp64, everything else in fp32.  Normals are updated in place when
+    pts already lives on the device (the reference's own in-place contract, orient_simple.py:24 relies on it,
+    holds for CPU tensors here as well); returns pts.  Trace: last_trace("points")."""
     lib = _lib.require_device()
     with torch.no_grad():
         dev = pts.device if pts.is_cuda else _compute_device()
-        work = pts.detach().to(device=dev, dtype=torch.float32).contiguous()
+        wd = torch.float64 if pts.dtype == torch.float64 else torch.float32
+        work = pts.detach().to(device=dev, dtype=wd).contiguous()
         if work.data_ptr() == pts.data_ptr():
             work = work.clone()
         N = work.shape[0]
         order = torch.empty(N, dtype=torch.int64, device=dev)
         done = False
-        if N < lib.dnp_point_greedy_max_points():
+        if N < lib.dnp_point_greedy_max_points() and N <= POINT_GREEDY_MAX_PER_GROUP[wd] * _cu_count(dev):
             # one persistent launch: a single workgroup up to 2048 points, one workgroup per CU beyond
-            nbytes = lib.dnp_point_greedy_workspace_bytes(N)
+            nbytes = lib.dnp_point_greedy_workspace_bytes(N, work.element_size())
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            backup = work.clone() if N > 2048 else None   # the multi-workgroup form may time out on a shared GPU
-            with torch.cuda.device(dev):
-                rc = lib.dnp_point_greedy_f32(_lib.ptr(work), N, work.stride(0), int(starting_point), 1e-6,
-                                              int(bool(diffuse)), _lib.ptr(order), None, _lib.ptr(ws), nbytes,
-                                              _lib.current_stream())
+            fn = lib.dnp_point_greedy_f64 if wd == torch.float64 else lib.dnp_point_greedy_f32
+            with _on_device(dev):
+                rc = fn(_lib.ptr(work), N, work.stride(0), int(starting_point), 1e-6, int(bool(diffuse)),
+                        _lib.ptr(order), None, int(POINT_GREEDY_FORM), int(POINT_GREEDY_GROUPS), _lib.ptr(ws), nbytes,
+                        _lib.current_stream())
             _lib.check(rc)
             done = True
-            if backup is not None and int(ws[:4].view(torch.int32).item()) != 0:
-                # the multi-workgroup form needs every workgroup resident; if the GPU was shared and a spin
-                # timed out, redo the propagation step by step
+            if N > 2048 and int(ws[:4].view(torch.int32).item()) != 0:
+                # a workgroup of the multi-workgroup form gave up waiting for its peers (GPU shared with another
+                # process): the kernel left pts untouched; redo the propagation step by step
                 print("warning: persistent per-point kernel timed out, falling back to step-wise launches")
-                work = backup
                 done = False
         if not done:
             order = _points_stepwise(work, diffuse, int(starting_point))
         pts[:, 3:] = work[:, 3:].to(device=pts.device, dtype=pts.dtype)
-        strongest_field_propagation_points.last_trace = dict(order=order)
+        _set_trace("points", order=order)
         return pts
+
+
+# form / workgroup cap handed to dnp_point_greedy_* (0 = let the library choose); tests pin them to cover both forms
+POINT_GREEDY_FORM = 0
+POINT_GREEDY_GROUPS = 0
+POINT_GREEDY_MAX_PER_GROUP = {torch.float32: 512 * 20, torch.float64: 512 * 8}
+_cu_cache = {}
+
+
+def _cu_count(dev) -> int:
+    n = _cu_cache.get(dev.index)
+    if n is None:
+        n = _cu_cache[dev.index] = min(256, torch.cuda.get_device_properties(dev).multi_processor_count)
+    return n
 
 
 def _points_stepwise(work, diffuse, start):
@@ -656,7 +823,7 @@ def _points_stepwise(work, diffuse, start):
     field_utils.py:361-380 with one single-source field launch per step."""
     dev = work.device
     N = work.shape[0]
-    E = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+    E = torch.zeros((N, 3), dtype=work.dtype, device=dev)
     visited = torch.zeros(N, dtype=torch.bool, device=dev)
     order = torch.empty(N, dtype=torch.int64, device=dev)
     cur = start
@@ -672,7 +839,7 @@ def _points_stepwise(work, diffuse, start):
         if float(inter[cur]) < 0:
             work[cur, 3:] *= -1
     if diffuse:
-        s = ((E * work[:, 3:]).sum(dim=-1) > 0).float() * 2 - 1
+        s = ((E * work[:, 3:]).sum(dim=-1) > 0).to(work.dtype) * 2 - 1
         work[:, 3:] = work[:, 3:] * s[:, None]
     return order
 

@@ -60,7 +60,11 @@ def gather_rows(W_local: torch.Tensor, bounds: np.ndarray, group=None) -> torch.
 
 
 def reduce_field(E_partial: torch.Tensor, group=None) -> torch.Tensor:
-    """Sum the per-rank partial fields (each rank combined its own slabs) on every rank."""
+    """Sum the per-rank partial fields (each rank combined its own slabs, in fp64) on every rank.  The partial
+    sums are fp64 sums of +-1-signed fp32 slabs, so the total is independent of the split over ranks up to
+    fp64 reassociation (~1e-16 relative): after the single rounding to fp32 the field - and every sign taken
+    from it - is the one a single GPU computes, except when a component lies within that distance of a
+    rounding boundary (probability ~1e-9 per component)."""
     _, size = world()
     if size > 1:
         if _host_staged(E_partial):
@@ -72,11 +76,25 @@ def reduce_field(E_partial: torch.Tensor, group=None) -> torch.Tensor:
     return E_partial
 
 
+def agree_on_start(start_t: torch.Tensor, group=None) -> torch.Tensor:
+    """Every rank uses rank 0's start patch.  The device PCA is deterministic, so the ranks compute the same
+    index anyway; the broadcast (8 bytes) makes the agreement unconditional."""
+    _, size = world()
+    if size > 1:
+        if _host_staged(start_t):
+            host = start_t.cpu()
+            dist.broadcast(host, src=0, group=group)
+            start_t.copy_(host)
+        else:
+            dist.broadcast(start_t, src=0, group=group)
+    return start_t
+
+
 def sharded_patch_propagation(pts: torch.Tensor, patches, all_patches, diffuse=False, weights=None,
                               start_patch: Optional[int] = None):
     """strongest_field_propagation (field_utils.py:286-348) with the per-patch fields sharded over
     the ranks of the default process group.  Every rank must call it with the same arguments; every
-    rank ends with the same oriented normals in `pts` (in place)."""
+    rank ends with the same oriented normals in `pts` (in place).  Trace: field_utils.last_trace("sharded")."""
     from . import field_utils as fu
 
     rank, size = world()
@@ -84,21 +102,14 @@ def sharded_patch_propagation(pts: torch.Tensor, patches, all_patches, diffuse=F
         if len(all_patches) == 0:
             return
         work, w = fu._prepare_work(pts, weights)
-        dev = work.device
-        if start_patch is None:
-            start_patch = fu._flattest_patch(work, [p.to(dev) for p in all_patches])
+        start_t = agree_on_start(fu._start_tensor(work, all_patches, start_patch))
         order, sigma, chosen, E, point_patch = fu._batched_patch_propagation(
-            work, list(all_patches), int(start_patch), diffuse, shard=(rank, size, gather_rows))
+            work, all_patches, start_t, diffuse, shard=(rank, size, gather_rows))
         if diffuse and E is not None:
             E = reduce_field(E)
-        sig = torch.tensor(sigma, dtype=torch.float32, device=dev)
-        flip = torch.ones(work.shape[0], dtype=torch.float32, device=dev)
-        inpatch = point_patch >= 0
-        flip[inpatch] = sig[point_patch[inpatch]]
+        flip = torch.where(point_patch >= 0, sigma[point_patch.clamp(min=0)], 1.0).to(torch.float32)
         work[:, 3:] = work[:, 3:] * flip[:, None]
         if diffuse:
-            fu._diffuse_sign_pass(work, E, [patch for _, patch in patches])
-        if w is not None:
-            work[:, 3:] = work[:, 3:] / w[:, None]
-        pts[:, 3:] = work[:, 3:].to(device=pts.device, dtype=pts.dtype)
-        sharded_patch_propagation.last_trace = dict(order=order, sigma=sigma, chosen=chosen, start=int(start_patch))
+            fu._diffuse_sign_pass(work, E.to(torch.float32), [patch for _, patch in patches])
+        fu._finish_patch_driver(pts, work, w)
+        fu._set_trace("sharded", order=order, sigma=sigma, chosen=chosen, start=start_t)

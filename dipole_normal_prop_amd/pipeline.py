@@ -56,7 +56,7 @@ def _partition(cloud, opts, stages):
     with stages("divide patches"):
         every = util.divide_pc(cloud[:, :3], opts.number_parts, min_patch=opts.minimum_points_per_patch)
     with stages("filter patches"):
-        kept = util.fix_n_filter(cloud, [rows.clone() for rows in every], opts.curvature_threshold)
+        kept = util.fix_n_filter(cloud, every, opts.curvature_threshold)
     print(f"number of patches {len(kept)}/{len(every)}")
     with stages("orient center"):
         util.orient_center_patches(cloud, [rows for _, rows in kept])

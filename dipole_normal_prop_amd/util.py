@@ -150,6 +150,32 @@ class Transform:
         return t.apply(pc), t
 
 
+# ---- patch lists -----------------------------------------------------------------------------------
+class PatchList(list):
+    """A list of per-patch index tensors (what the reference's callers pass around) that remembers its CSR
+    form: `flat` = the concatenated indices, `sizes` = the host-side patch sizes.  The entries are views into
+    `flat`, so drivers handed a PatchList need neither a torch.cat of hundreds of small tensors nor a device
+    round trip to learn the sizes."""
+
+    def __init__(self, flat: torch.Tensor, sizes):
+        self.flat = flat
+        self.sizes = [int(n) for n in sizes]
+        super().__init__(torch.split(flat, self.sizes) if len(self.sizes) else [])
+
+
+def patch_csr(patches, dev):
+    """(off[P+1] int64 on dev, idx[M] int64 on dev, sizes[P] numpy int64) of a list of index tensors."""
+    if isinstance(patches, PatchList) and len(patches) == len(patches.sizes):
+        sizes = np.asarray(patches.sizes, dtype=np.int64)
+        idx = patches.flat.to(device=dev, dtype=torch.int64)
+    else:
+        sizes = np.array([int(p.shape[0]) for p in patches], dtype=np.int64)
+        idx = torch.cat([p.to(device=dev, dtype=torch.int64) for p in patches]) if len(patches) else \
+            torch.zeros(0, dtype=torch.int64, device=dev)
+    off = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)).to(dev)
+    return off, idx, sizes
+
+
 # ---- voxel partition ---------------------------------------------------------------------------
 def _axis_bins(x: torch.Tensor, n_part: int, ranges) -> torch.Tensor:
     """Bin of every coordinate under the reference's test  lo_i < x <= hi_i  with
@@ -167,10 +193,11 @@ def _axis_bins(x: torch.Tensor, n_part: int, ranges) -> torch.Tensor:
     return torch.where(ok, cand_c, torch.full_like(cand_c, -1))
 
 
-def _divide_pc(pc_in: torch.Tensor, n_part: int, ranges=(-1.5, 1.5), min_patch: int = 0):
-    """Voxel partition: returns (indices, ijk) with one entry per non-empty cell, cells in
-    lexicographic (i, j, k) order and point indices ascending inside a cell - the order the
-    reference's triple loop produces.  Binning, sorting and splitting run on pc_in's device."""
+def _voxel_cells(pc_in: torch.Tensor, n_part: int, ranges=(-1.5, 1.5)):
+    """(order, keys, counts): `order` = the indices of the points that fall into a cell, sorted by cell in
+    lexicographic (i, j, k) order and ascending inside a cell (the order the reference's triple loop
+    produces, util.py:133-149); keys / counts = one entry per non-empty cell (host numpy).  Binning and
+    sorting run on pc_in's device; only the cell table crosses to the host."""
     bx = _axis_bins(pc_in[:, 0], n_part, ranges)
     by = _axis_bins(pc_in[:, 1], n_part, ranges)
     bz = _axis_bins(pc_in[:, 2], n_part, ranges)
@@ -178,60 +205,59 @@ def _divide_pc(pc_in: torch.Tensor, n_part: int, ranges=(-1.5, 1.5), min_patch: 
     m = n_part + 1
     key = (bx * m + by) * m + bz
     pts = torch.nonzero(inside).flatten()
-    if pts.numel() == 0:
-        return [], []
     skey, perm = torch.sort(key[pts], stable=True)
     order = pts[perm]
     ukeys, counts = torch.unique_consecutive(skey, return_counts=True)
-    indices = list(torch.split(order, counts.tolist()))
-    ijk = [(kk // (m * m), (kk // m) % m, kk % m) for kk in ukeys.tolist()]
-    return indices, ijk
+    table = torch.stack([ukeys, counts]).cpu().numpy()                 # ONE small device->host copy
+    return order, table[0].astype(np.int64), table[1].astype(np.int64)
 
 
-def merge_nodes(indices: List[torch.Tensor], ijk: List[Tuple[int, int, int]], min_patch: int):
-    """Merge cells with fewer than min_patch points into a neighbouring cell (26-neighbourhood of
-    any of its constituent cells).  Mirrors the reference's procedure including its order
-    dependence: up to 10 sweeps over the cells in order; a small cell is appended to the LAST
-    (highest index) live cell that touches it; cells still below min_patch at the end are dropped."""
-    pts = [[t] for t in indices]               # list of tensors per live cell (concatenated at the end)
-    size = [int(t.shape[0]) for t in indices]
-    cells = [[c] for c in ijk]                 # constituent voxel coordinates per live cell
-    live = [True] * len(indices)
+def _keys_to_ijk(keys: np.ndarray, n_part: int) -> np.ndarray:
+    m = n_part + 1
+    return np.stack([keys // (m * m), (keys // m) % m, keys % m], axis=1).astype(np.int32)
 
-    def touches(a, b):
-        for ca in a:
-            for cb in b:
-                if abs(ca[0] - cb[0]) <= 1 and abs(ca[1] - cb[1]) <= 1 and abs(ca[2] - cb[2]) <= 1:
-                    return True
-        return False
 
-    sweeps, again = 0, True
-    while again and sweeps < 10:
-        again = False
-        sweeps += 1
-        for i in range(len(cells)):
-            if not live[i] or size[i] >= min_patch:
-                continue
-            target = -1
-            for j in range(len(cells)):
-                if j != i and live[j] and touches(cells[i], cells[j]):
-                    target = j
-            if target < 0:
-                continue
-            pts[target].extend(pts[i])
-            size[target] += size[i]
-            cells[target].extend(cells[i])
-            live[i] = False
-            pts[i], cells[i], size[i] = [], [], 0
-            if size[target] < min_patch:
-                again = True
-    if sweeps == 10:
+def _divide_pc(pc_in: torch.Tensor, n_part: int, ranges=(-1.5, 1.5), min_patch: int = 0):
+    """Voxel partition (util.py:110-150): returns (indices, ijk) with one entry per non-empty cell, cells in
+    lexicographic (i, j, k) order and point indices ascending inside a cell."""
+    order, keys, counts = _voxel_cells(pc_in, n_part, ranges)
+    if keys.size == 0:
+        return [], []
+    return PatchList(order, counts), [tuple(int(v) for v in row) for row in _keys_to_ijk(keys, n_part)]
+
+
+def merge_cells(ijk: np.ndarray, sizes: np.ndarray, min_patch: int):
+    """The reference's order-dependent merge of small cells (util.merge_nodes, util.py:448-492) on the cell
+    table: (seq, seq_off) = original cell ids grouped by surviving patch, in concatenation order.  Runs in
+    the native library (host code: the procedure is sequential by definition)."""
+    from . import _lib
+    lib = _lib.load()
+    C = int(len(sizes))
+    ijk = np.ascontiguousarray(ijk, dtype=np.int32).reshape(C, 3)
+    sizes = np.ascontiguousarray(sizes, dtype=np.int64)
+    seq = np.empty(max(C, 1), dtype=np.int64)
+    seq_off = np.empty(C + 1, dtype=np.int64)
+    n_out = np.zeros(1, dtype=np.int64)
+    sweeps = np.zeros(1, dtype=np.int32)
+    _lib.check(lib.dnp_merge_cells(ijk.ctypes.data, sizes.ctypes.data, C, int(min_patch), seq.ctypes.data,
+                                   seq_off.ctypes.data, n_out.ctypes.data, sweeps.ctypes.data))
+    if int(sweeps[0]) == 10:
         print("recursive merge failed to merge some patches")
-    out_idx, out_cells = [], []
-    for i in range(len(cells)):
-        if live[i] and size[i] >= min_patch:
-            out_idx.append(torch.cat(pts[i]))
-            out_cells.append(cells[i])
+    n = int(n_out[0])
+    return seq[: int(seq_off[n])], seq_off[: n + 1]
+
+
+def merge_nodes(indices: List[torch.Tensor], ijk, min_patch: int):
+    """Merge cells with fewer than min_patch points into a neighbouring cell (26-neighbourhood of any of its
+    constituent cells), as util.merge_nodes (util.py:448-492) including its order dependence: up to 10 sweeps
+    over the cells in order; a small cell is appended to the LAST (highest index) live cell that touches it;
+    cells still below min_patch at the end are dropped.  Returns (patches, constituent cells per patch)."""
+    sizes = np.array([int(t.shape[0]) for t in indices], dtype=np.int64)
+    cells = np.asarray(ijk, dtype=np.int32).reshape(len(indices), 3)
+    seq, seq_off = merge_cells(cells, sizes, min_patch)
+    out_idx = [torch.cat([indices[c] for c in seq[seq_off[g]:seq_off[g + 1]]]) for g in range(len(seq_off) - 1)]
+    out_cells = [[tuple(int(v) for v in cells[c]) for c in seq[seq_off[g]:seq_off[g + 1]]]
+                 for g in range(len(seq_off) - 1)]
     return out_idx, out_cells
 
 
@@ -239,51 +265,91 @@ def divide_pc(pc_in: torch.Tensor, n_part: int, ranges=(-1.5, 1.5), min_patch: i
     """Voxel partition followed by the merge of small patches: the behaviour the reference's
     callers rely on (`[x.clone() for x in patch_indices]`).  NOTE: the reference's divide_pc as
     committed (util.py:338-341) skips the merge and returns list-wrapped tensors, which makes
-    its own callers raise; this is the evidently intended composition."""
-    indices, ijk = _divide_pc(pc_in, n_part, ranges, min_patch)
-    merged, _ = merge_nodes(indices, ijk, min_patch)
-    return merged
+    its own callers raise; this is the evidently intended composition.
+
+    The points are binned and sorted by cell on pc_in's device, the cell table (a few thousand rows) is
+    merged on the host, and ONE gather assembles every patch's index list; the result is a PatchList."""
+    order, keys, counts = _voxel_cells(pc_in, n_part, ranges)
+    if keys.size == 0:
+        return PatchList(order, [])
+    seq, seq_off = merge_cells(_keys_to_ijk(keys, n_part), counts, min_patch)
+    starts = np.concatenate([[0], np.cumsum(counts)])[:-1]
+    sz = counts[seq]
+    sizes = np.add.reduceat(sz, seq_off[:-1]) if len(seq_off) > 1 else np.zeros(0, dtype=np.int64)
+    total = int(sz.sum())
+    # position p of the output reads order[starts[cell] + (p - first output position of that cell)]
+    out_first = np.concatenate([[0], np.cumsum(sz)])[:-1]
+    shift = torch.from_numpy((starts[seq] - out_first).astype(np.int64)).to(order.device)
+    reps = torch.from_numpy(sz.astype(np.int64)).to(order.device)
+    pos = torch.arange(total, device=order.device) + torch.repeat_interleave(shift, reps, output_size=total)
+    return PatchList(order[pos], sizes)
 
 
 def pca_eigen_values(x: torch.Tensor):
-    """(smallest covariance eigenvalue as a 1-element tensor, its eigenvector) of x[:, :3]."""
+    """(smallest covariance eigenvalue as a 1-element tensor, its eigenvector) of x[:, :3]
+    (util.pca_eigen_values, util.py:495-500), in x's precision like the reference."""
     rel = x[:, :3] - x.mean(dim=0)[None, :3]
     cov = (rel.transpose(0, 1) @ rel) / x.shape[0]
     e, v = torch.linalg.eigh(cov)   # ascending; the reference's torch.symeig is gone in torch >= 2
     return e[0:1], v[:, 0]
 
 
-def _patch_covariances(pc: torch.Tensor, patches: List[torch.Tensor]):
-    """(pid[M], idx[M], mean[P,3], cov[P,3,3]) of the xyz of every listed patch, by two segmented sums."""
+def patch_pca(pc: torch.Tensor, patches):
+    """(mean[P,3], evals[P,3] ascending, evecs[P,3,3], csr) of cov = (x - mean)^T (x - mean) / n of every
+    listed patch, in fp64 from pc's coordinates, deterministic.  evecs[p][:, k] is eigenvector k with its
+    largest-magnitude component positive (the sign is arbitrary in the reference: LAPACK's).  This is the ONE
+    place patch covariances are formed: the start-patch rule (field_utils.py:230-233, :303-306), the flatness
+    filter (inference_utils.py:52-71) and orient_center (util.py:39-44) all read it.  Device clouds run the
+    dnp_patch_pca kernel (one workgroup per patch); CPU clouds the same arithmetic in torch."""
     dev = pc.device
-    P = len(patches)
-    sizes = torch.tensor([int(p.shape[0]) for p in patches], device=dev)
-    idx = torch.cat([p.to(dev) for p in patches]) if P else torch.zeros(0, dtype=torch.long, device=dev)
-    pid = torch.repeat_interleave(torch.arange(P, device=dev), sizes)
-    xyz = pc[idx, :3]
-    cnt = sizes.to(xyz.dtype).clamp(min=1)[:, None]
-    mean = torch.zeros((P, 3), dtype=xyz.dtype, device=dev).index_add_(0, pid, xyz) / cnt
+    off, idx, sizes = patch_csr(patches, dev)
+    P = len(sizes)
+    mean = torch.empty((P, 3), dtype=torch.float64, device=dev)
+    evals = torch.empty((P, 3), dtype=torch.float64, device=dev)
+    evecs = torch.empty((P, 3, 3), dtype=torch.float64, device=dev)
+    if P == 0:
+        return mean, evals, evecs, (off, idx, sizes)
+    if pc.is_cuda:
+        from . import _lib
+        lib = _lib.require_device()
+        src = pc if pc.dtype in (torch.float32, torch.float64) else pc.float()
+        if src.stride(1) != 1:
+            src = src.contiguous()
+        fn = lib.dnp_patch_pca_f64 if src.dtype == torch.float64 else lib.dnp_patch_pca_f32
+        with torch.cuda.device(dev):
+            _lib.check(fn(_lib.ptr(src), src.stride(0), _lib.ptr(off), _lib.ptr(idx), P, _lib.ptr(mean),
+                          _lib.ptr(evals), _lib.ptr(evecs), _lib.current_stream()))
+        return mean, evals, evecs, (off, idx, sizes)
+    pid = torch.repeat_interleave(torch.arange(P), torch.from_numpy(sizes))
+    xyz = pc[idx, :3].double()
+    cnt = torch.from_numpy(sizes).double().clamp(min=1)[:, None]
+    mean = torch.zeros((P, 3), dtype=torch.float64).index_add_(0, pid, xyz) / cnt
     rel = xyz - mean[pid]
     outer = (rel[:, :, None] * rel[:, None, :]).reshape(-1, 9)
-    cov = (torch.zeros((P, 9), dtype=xyz.dtype, device=dev).index_add_(0, pid, outer) / cnt).reshape(P, 3, 3)
-    return pid, idx, mean, cov
+    cov = (torch.zeros((P, 9), dtype=torch.float64).index_add_(0, pid, outer) / cnt).reshape(P, 3, 3)
+    evals, evecs = torch.linalg.eigh(cov)
+    big = evecs.abs().argmax(dim=1, keepdim=True)                       # [P,1,3]: row of the largest component
+    sgn = torch.where(torch.gather(evecs, 1, big) < 0, -1.0, 1.0)
+    return mean, evals, evecs * sgn, (off, idx, sizes)
 
 
 def fix_n_filter(input_pc: torch.Tensor, patch_indices: List[torch.Tensor], threshold: float):
     """Keep patches whose flatness ratio e0 / (e1 + e2/2) exceeds threshold as (i, idx) pairs; the
     others get their normals aligned with their own PCA normal in place
-    (inference_utils.py:52-71 - pure torch, on the callers' path).  All covariances come from two
-    segmented sums and one batched eigh instead of one eigh per patch."""
+    (inference_utils.py:52-71 - pure torch, on the callers' path).  One patch_pca call for all patches;
+    only the P keep flags cross to the host (the return value is a Python list)."""
     if len(patch_indices) == 0:
         return []
-    pid, idx, _, cov = _patch_covariances(input_pc, patch_indices)
-    e, v = torch.linalg.eigh(cov.cpu())
+    _, e, v, (off, idx, sizes) = patch_pca(input_pc, patch_indices)
     keep = (e[:, 0] / (e[:, 1] + e[:, 2] / 2)) > threshold
-    kept = [(i, patch) for i, patch in enumerate(patch_indices) if bool(keep[i])]
-    drop = ~keep.to(input_pc.device)
-    if bool(drop.any()):
-        sel = drop[pid]
-        rows, normal = idx[sel], v[:, :, 0].to(input_pc.device, input_pc.dtype)[pid[sel]]
+    keep_host = keep.cpu().numpy()
+    kept = [(i, patch) for i, patch in enumerate(patch_indices) if bool(keep_host[i])]
+    if not keep_host.all():
+        P = len(sizes)
+        pid = torch.repeat_interleave(torch.arange(P, device=input_pc.device),
+                                      torch.from_numpy(sizes).to(input_pc.device), output_size=int(sizes.sum()))
+        sel = ~keep[pid]
+        rows, normal = idx[sel], v[:, :, 0].to(input_pc.dtype)[pid[sel]]
         s = ((input_pc[rows, 3:] * normal).sum(dim=-1) > 0).to(input_pc.dtype) * 2 - 1
         input_pc[rows, 3:] = input_pc[rows, 3:] * s[:, None]
     return kept
@@ -294,13 +360,15 @@ def orient_center_patches(input_pc: torch.Tensor, patches: List[torch.Tensor]) -
     patches in one pass: flip the normals that point towards their patch's centroid."""
     if len(patches) == 0:
         return
-    allidx = torch.cat([p.to(input_pc.device) for p in patches])
-    if torch.bincount(allidx, minlength=input_pc.shape[0]).max() > 1:      # overlapping lists: literal loop
+    mean, _, _, (off, idx, sizes) = patch_pca(input_pc, patches)
+    if torch.bincount(idx, minlength=input_pc.shape[0]).max() > 1:      # overlapping lists: literal loop
         for p in patches:
             input_pc[p] = orient_center(input_pc[p])
         return
-    pid, idx, mean, _ = _patch_covariances(input_pc, patches)
-    inward = ((input_pc[idx, :3] - mean[pid]) * input_pc[idx, 3:]).sum(dim=-1) < 0
+    pid = torch.repeat_interleave(torch.arange(len(sizes), device=input_pc.device),
+                                  torch.from_numpy(sizes).to(input_pc.device), output_size=int(sizes.sum()))
+    rel = input_pc[idx, :3] - mean.to(input_pc.dtype)[pid]
+    inward = (rel * input_pc[idx, 3:]).sum(dim=-1) < 0
     rows = idx[inward]
     input_pc[rows, 3:] = -input_pc[rows, 3:]
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DNP_VERSION 100 /* 0.1.0 */
+#define DNP_VERSION 200 /* 0.2.0 */
 
 enum {
     DNP_OK = 0,
@@ -60,20 +60,22 @@ const char* dnp_last_error(void);      /* thread-local, never NULL */
  *
  * out row for target j is  out + (out_scatter ? tgt_idx[j] : j) * ld_out  (3 floats);
  * accumulate != 0 adds to what is there (E[mask] = E[mask] + dE, field_utils.py:331).
+ * nonfinite (device int32[2], may be NULL): [0] += number of Inf, [1] += number of NaN leaf components that
+ * were zeroed - what the reference prints as "warning: %d inf/nan in field_grad" (field_utils.py:110-113).
  */
 size_t dnp_field_grad_workspace_bytes(int64_t S, int64_t T, int64_t max_pts);
 
 int dnp_field_grad_f32(const float* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
                        const float* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
                        float eps, int64_t max_pts,
-                       float* out, int64_t ld_out, int out_scatter, int accumulate,
+                       float* out, int64_t ld_out, int out_scatter, int accumulate, int32_t* nonfinite,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* fp64 variant: the socket path of the reference feeds float64 clouds (util.py:71-77). */
 int dnp_field_grad_f64(const double* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
                        const double* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
                        double eps, int64_t max_pts,
-                       double* out, int64_t ld_out, int out_scatter, int accumulate,
+                       double* out, int64_t ld_out, int out_scatter, int accumulate, int32_t* nonfinite,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K2: dipole potential  (replaces field_utils.potential, field_utils.py:12-55) ------
@@ -142,16 +144,78 @@ int dnp_combine_fields_f32(const float* dE, int64_t K, int64_t N,
 /* ---- K4: per-point greedy propagation  (field_utils.strongest_field_propagation_points,
  *      field_utils.py:353-388) as ONE persistent launch.
  *
- * pts[N, >=6] normals are flipped in place; order_out[N] (device int64, may be NULL)
- * receives the visit order (order_out[0] = start).  E_out [N,3] (may be NULL) receives the
- * accumulated field.  diffuse != 0 applies the final per-point sign pass (:382-385).
+ * pts[N, >=6] normals are flipped in place (the kernels write the oriented normals to scratch and a
+ * stream-ordered second kernel copies them into pts, so no workgroup ever reads a row another one is
+ * rewriting); order_out[N] (device int64, may be NULL) receives the visit order (order_out[0] = start).
+ * E_out [N,3] (may be NULL) receives the accumulated field.  diffuse != 0 applies the final per-point sign
+ * pass (:382-385).  _f64 is the same propagation in double precision: the reference's socket path hands
+ * float64 clouds to this driver (util.py:71-77, socket_server.py:18-27).
+ *
+ * form: 0 = choose by N, 1 = single workgroup (N <= 512*20 fp32 / 512*8 fp64), 2 = one workgroup per CU
+ * (cooperative launch; N < 2^20).  max_groups > 0 caps the workgroup count of form 2.  The first int of the
+ * workspace is a status word: non-zero after the launch means a workgroup of form 2 gave up waiting for its
+ * peers (GPU shared with another process); pts is then unchanged garbage-free input and the caller should fall
+ * back to step-wise launches of dnp_field_grad.
  */
-size_t dnp_point_greedy_workspace_bytes(int64_t N);
-int dnp_point_greedy_max_points(void);   /* capacity of the single-workgroup persistent form */
+size_t dnp_point_greedy_workspace_bytes(int64_t N, int elem_size /* 4 or 8 */);
+int dnp_point_greedy_max_points(void);   /* capacity of the persistent forms: N < this */
 
 int dnp_point_greedy_f32(float* pts, int64_t N, int64_t ld_pts, int64_t start, float eps,
-                         int diffuse, int64_t* order_out, float* E_out,
+                         int diffuse, int64_t* order_out, float* E_out, int form, int max_groups,
                          void* workspace, size_t workspace_bytes, void* stream);
+int dnp_point_greedy_f64(double* pts, int64_t N, int64_t ld_pts, int64_t start, double eps,
+                         int diffuse, int64_t* order_out, double* E_out, int form, int max_groups,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- per-patch PCA  (util.pca_eigen_values util.py:495-500; the start-patch rule
+ *      field_utils.py:230-233 / :303-306; inference_utils.fix_n_filter :52-71; util.orient_center :39-44)
+ *
+ * For every patch of the CSR partition (patch_idx == NULL: contiguous row ranges): mean[P,3], the
+ * eigenvalues of cov = (x - mean)^T (x - mean) / n in ascending order evals[P,3] and the eigenvectors
+ * evecs[P,3,3] (evecs[p][c][k] = component c of eigenvector k, i.e. torch.linalg.eigh's layout), all in
+ * fp64 from the fp32/fp64 coordinates, deterministic (fixed reduction tree, no atomics).  An eigenvector's
+ * sign is arbitrary in the reference (LAPACK's choice); here its largest-magnitude component is positive.
+ * One workgroup per patch.
+ */
+int dnp_patch_pca_f32(const float* pts, int64_t ld_pts, const int64_t* patch_off, const int64_t* patch_idx,
+                      int64_t P, double* mean, double* evals, double* evecs, void* stream);
+int dnp_patch_pca_f64(const double* pts, int64_t ld_pts, const int64_t* patch_off, const int64_t* patch_idx,
+                      int64_t P, double* mean, double* evals, double* evecs, void* stream);
+
+/* ---- the greedy loop on the interaction matrix  (field_utils.py:314-324, :242-254) -----------------
+ *
+ * With W from dnp_interactions_f32 (all P rows):  I_j = sum_{k visited} sigma_k W[k][j]; every step takes the
+ * first maximum of |I_j| over the unvisited patches in patch order (torch.argmax over the reference's
+ * `remaining` list), sets sigma_j = -1 when I_j < 0 and adds sigma_j W[j] to I.  start is a DEVICE int64
+ * (so that a start patch chosen on the device needs no host round trip).  Outputs (device): order[P],
+ * sigma[P] (+-1.0), chosen[P-1] (the signed interaction of each chosen patch).  One wavefront; P <=
+ * dnp_patch_greedy_max_patches().
+ */
+int dnp_patch_greedy_max_patches(void);
+int dnp_patch_greedy(const double* W, int64_t P, const int64_t* start, int64_t* order, double* sigma,
+                     double* chosen, void* stream);
+
+/* E[t] (+)= sum_{k=0..K-1} sigma[p_lo + k] * dE[k][t]  for the K slabs held here (patches p_lo .. p_lo+K-1),
+ * accumulated in DOUBLE in slab order (E is [N,3] doubles): the diffuse field of the batched drivers
+ * (field_utils.py:330-331) from the device outputs of dnp_patch_greedy.  sigma is +-1, so the products are
+ * exact and the fp64 sum does not depend on the visit order or on how the patches are split over GPUs (the
+ * reference's own fp32 chain E = E + dE in visit order is dnp_combine_fields_f32). */
+int dnp_combine_signed_f32(const float* dE, int64_t K, int64_t N, const double* sigma, int64_t P, int64_t p_lo,
+                           double* E, int accumulate, void* stream);
+
+/* ---- merge of small voxel cells  (util.merge_nodes, util.py:448-492) - HOST function, host pointers ----
+ *
+ * cell_ijk[C,3] (int32 voxel coordinates in [0, 2^20)) and cell_size[C] describe the non-empty cells of the
+ * voxel partition in the reference's (i, j, k)-lexicographic order.  Up to 10 sweeps over the cells in
+ * order; a cell with fewer than min_patch points is appended to the LAST (highest index) other live cell
+ * that has a voxel in the 26-neighbourhood of one of its voxels (the reference's find_dij keeps overwriting
+ * its result, so the last match wins); cells still below min_patch at the end are dropped.  Output:
+ * seq[C] = original cell ids grouped by surviving patch in concatenation order, seq_off[n_out + 1] the
+ * group boundaries (room for C + 1 entries), *sweeps_out the number of sweeps made (10 = the reference
+ * prints "recursive merge failed to merge some patches").  Sequential by definition; no device work.
+ */
+int dnp_merge_cells(const int32_t* cell_ijk, const int64_t* cell_size, int64_t C, int64_t min_patch,
+                    int64_t* seq, int64_t* seq_off, int64_t* n_out, int32_t* sweeps_out);
 
 /* ---- the fork's "xie" pair functions -----------------------------------------
  *

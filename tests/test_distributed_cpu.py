@@ -17,10 +17,10 @@ from oracle import dipole_oracle as O
 
 
 class OracleStandIn:
-    """CPU stand-ins for the three device entry wrappers (dnp_patch_fields_f32 / dnp_interactions_f32 /
-    dnp_combine_fields_f32).  The worker processes of this test patch them into field_utils so that the
-    partition / gather / reduce plumbing of the N>1 path can run without a GPU; the product code itself has
-    no such switch."""
+    """CPU stand-ins for the device entry wrappers (dnp_patch_fields_f32 / dnp_interactions_f32 /
+    dnp_patch_greedy / dnp_combine_signed_f32).  The worker processes of this test patch them into field_utils
+    so that the partition / gather / reduce plumbing of the N>1 path can run without a GPU; the product code
+    itself has no such switch."""
 
     @staticmethod
     def slabs(work, off, idx, point_patch, b0, b1, eps, extent=None):
@@ -42,11 +42,17 @@ class OracleStandIn:
                             for k in range(dE.shape[0])])
 
     @staticmethod
-    def combine(dE, coef, slab, E, accumulate):
+    def greedy(W, start_t):
+        from dipole_normal_prop_amd import field_utils as fu
+        order, sigma, chosen = fu.greedy_order_from_interactions(W.numpy(), int(start_t[0]))
+        return torch.from_numpy(order), torch.from_numpy(sigma), torch.from_numpy(chosen)
+
+    @staticmethod
+    def combine_signed(dE, sigma, p_lo, E64, accumulate):
         if not accumulate:
-            E.zero_()
-        for c, s in zip(coef.tolist(), slab.tolist()):
-            E += c * dE[s]
+            E64.zero_()
+        for k in range(dE.shape[0]):
+            E64 += float(sigma[p_lo + k]) * dE[k].double()
 
 
 def _case():
@@ -60,7 +66,7 @@ def _case():
     return cloud, patches
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, start, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -68,12 +74,12 @@ def _worker(rank, world, port, q):
         cloud, patches = _case()
         pts = cloud.clone()
         from dipole_normal_prop_amd import field_utils as fu
-        fu._patch_slabs, fu._interaction_rows, fu._combine = OracleStandIn.slabs, OracleStandIn.interactions, \
-            OracleStandIn.combine
+        fu._patch_slabs, fu._interaction_rows = OracleStandIn.slabs, OracleStandIn.interactions
+        fu._greedy_on_device, fu._combine_signed = OracleStandIn.greedy, OracleStandIn.combine_signed
         fu._prepare_work = lambda p, w: (p.detach().clone().float(), None)       # CPU working copy (no weights here)
-        parallel.sharded_patch_propagation(pts, list(enumerate(patches)), patches, diffuse=True, start_patch=3)
-        tr = parallel.sharded_patch_propagation.last_trace
-        q.put((rank, pts[:, 3:].numpy().copy(), tr["order"].copy(), tr["sigma"].copy()))
+        parallel.sharded_patch_propagation(pts, list(enumerate(patches)), patches, diffuse=True, start_patch=start)
+        tr = fu.last_trace("sharded")
+        q.put((rank, pts[:, 3:].numpy().copy(), tr["order"].copy(), tr["sigma"].copy(), tr["start"]))
     finally:
         dist.destroy_process_group()
 
@@ -86,20 +92,27 @@ def _free_port():
     return p
 
 
-def test_two_ranks_reproduce_the_single_process_result():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("start", [3, None])
+def test_two_ranks_reproduce_the_single_process_result(start):
+    """start = None: every rank finds the flattest patch itself (deterministic fp64 PCA) and rank 0's choice is
+    broadcast - the ranks must agree with each other and with the oracle's own default start."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, start, q)) for r in range(world)]
     [p.start() for p in procs]
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     cloud, patches = _case()
     ref_pts, ref_tr = O.strongest_field_propagation(cloud, list(enumerate(patches)), patches, diffuse=True,
-                                                    start_patch=3)
-    for rank, normals, order, sigma in res:
+                                                    start_patch=start)
+    for rank, normals, order, sigma, used_start in res:
+        assert used_start == int(ref_tr["order"][0])
         assert np.array_equal(order, ref_tr["order"])
         assert np.array_equal((sigma < 0)[order], ref_tr["flipped"])
         assert np.array_equal(normals, ref_pts[:, 3:].numpy())

@@ -268,9 +268,8 @@ def test_patch_fields_interactions_and_combine(dev):
     pts = t(g["pc_patchflip"]).to(dev)
     allp = csr_to_list(g["patch_off"], g["patch_idx"])
     N, P = pts.shape[0], len(allp)
-    off, idx = fu._csr(allp, dev)
-    point_patch = torch.full((N,), -1, dtype=torch.int64, device=dev)
-    point_patch[idx] = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
+    off, idx, sizes = util.patch_csr(allp, dev)
+    point_patch = fu._point_patch_ids(idx, sizes, N)
     dE = fu._patch_slabs(pts, off, idx, point_patch, 0, P, 1e-5)
     assert dE.shape == (P, N, 3)
     cpu = pts.cpu()
@@ -306,6 +305,16 @@ def test_patch_fields_interactions_and_combine(dev):
     for i in range(P):
         ref = ref + coef[i].item() * dE[order[i]]
     assert torch.equal(E, ref)
+    # signed fp64 combination (what the batched drivers use): any split of the slabs over "ranks" adds up
+    sig = coef.double().to(dev)
+    E64 = torch.empty(N, 3, dtype=torch.float64, device=dev)
+    fu._combine_signed(dE, sig, 0, E64, False)
+    want = (dE.double() * sig[:, None, None]).sum(dim=0)
+    assert float((E64 - want).abs().max()) <= 1e-12 * float(want.abs().max())
+    parts = torch.zeros(N, 3, dtype=torch.float64, device=dev)
+    for lo, hi in ((0, 20), (20, 21), (21, P)):
+        fu._combine_signed(dE[lo:hi], sig, lo, parts, True)
+    assert torch.equal(parts.float(), E64.float())
 
 
 # ---- greedy drivers against the reference's traces -----------------------------------------------------
@@ -325,19 +334,19 @@ ALL_G6 = [f"{c}_{d}_{w}" for c in ("pf", "sc") for d in ("n", "d") for w in ("nw
 @pytest.mark.parametrize("tag", ALL_G6)
 def test_G6_patch_propagation(dev, tag, mode, monkeypatch):
     """BASELINE config 2 driver: fandisk, 72 patches (n_part 30, min 100), every diffuse/weights
-    combination: visit order, flip decisions, chosen interactions and final signs of the reference."""
+    combination: start patch (the driver's own choice - nothing is pinned), visit order, flip decisions,
+    chosen interactions and final signs of the reference."""
     g = load_golden("G6_patch_propagation")
     cloud, patches, allp, diffuse, w = _patch_case(g, tag)
     if mode == "sequential" and tag not in ("pf_d_w", "sc_n_nw"):
         pytest.skip("sequential form is covered on two representative cases")
     monkeypatch.setattr(fu, "PATCH_MODE", mode)
     pts = cloud.clone().to(dev)
-    start = int(g[f"order_{tag}"][0])
     ret = fu.strongest_field_propagation(pts, [(i, p.to(dev)) for i, p in patches], [p.to(dev) for p in allp],
-                                         diffuse=diffuse, weights=None if w is None else w.to(dev),
-                                         start_patch=start)
+                                         diffuse=diffuse, weights=None if w is None else w.to(dev))
     assert ret is None                                               # in place, returns None
-    tr = fu.strongest_field_propagation.last_trace
+    tr = fu.last_trace("patches")
+    assert tr["start"] == int(g[f"order_{tag}"][0])
     assert np.array_equal(tr["order"], g[f"order_{tag}"])
     assert np.array_equal((tr["sigma"] < 0)[tr["order"]], g[f"flipped_{tag}"])
     assert np.allclose(tr["chosen"], g[f"chosen_{tag}"], rtol=2e-4)
@@ -347,16 +356,68 @@ def test_G6_patch_propagation(dev, tag, mode, monkeypatch):
     assert torch.equal(out[:, :3], cloud[:, :3])
 
 
-def test_G6_default_start_patch_and_cpu_tensor_input(dev):
+@pytest.mark.parametrize("tag", ["pf_d_nw", "sc_n_w"])
+def test_G6_cpu_tensor_input_default_start(dev, tag):
+    """CPU tensors in (like the reference's CPU run): staged to the device, same start patch, trace and signs."""
     g = load_golden("G6_patch_propagation")
-    cloud, patches, allp, diffuse, w = _patch_case(g, "pf_d_nw")
-    pts = cloud.clone()                                              # CPU tensor, like the reference's CPU run
-    fu.strongest_field_propagation(pts, patches, allp, diffuse=True)
-    tr = fu.strongest_field_propagation.last_trace
-    curv = np.abs(g["curv"])
-    assert curv[tr["start"]] <= curv.min() + 1e-9                    # flattest patch up to fp32 eigen noise
-    if tr["start"] == int(g["order_pf_d_nw"][0]):
-        assert np.array_equal(((pts[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g["sign_pf_d_nw"])
+    cloud, patches, allp, diffuse, w = _patch_case(g, tag)
+    pts = cloud.clone()
+    fu.strongest_field_propagation(pts, patches, allp, diffuse=diffuse, weights=w)
+    tr = fu.last_trace("patches")
+    assert tr["start"] == int(g[f"order_{tag}"][0])
+    assert np.array_equal(tr["order"], g[f"order_{tag}"])
+    assert pts.device.type == "cpu"
+    assert np.array_equal(((pts[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g[f"sign_{tag}"])
+
+
+def test_start_patch_rule_matches_the_reference_curvatures(dev):
+    """The device PCA behind the start-patch rule against the reference's own per-patch |lambda_min| (G6 `curv`,
+    util.pca_eigen_values in fp32): same values up to fp32 eigen noise, same argmin; device and CPU paths of
+    util.patch_pca agree to fp64 rounding; the kernel is deterministic."""
+    g = load_golden("G6_patch_propagation")
+    cloud = t(g["pc_patchflip"])
+    allp = csr_to_list(g["patch_off"], g["patch_idx"])
+    m_d, e_d, v_d, _ = util.patch_pca(cloud.to(dev), [p.to(dev) for p in allp])
+    m_c, e_c, v_c, _ = util.patch_pca(cloud, allp)
+    assert e_d.dtype == torch.float64 and e_d.shape == (72, 3)
+    scale = float(e_c.abs().max())
+    assert float((e_d.cpu() - e_c).abs().max()) < 1e-13 * scale
+    assert float((m_d.cpu() - m_c).abs().max()) < 1e-14
+    assert float((v_d.cpu() - v_c).abs().max()) < 1e-6              # same sign convention on both paths
+    assert np.abs(e_d[:, 0].cpu().numpy() - g["curv"]).max() < 2e-6 * scale
+    assert int(torch.argmin(e_d[:, 0].abs())) == int(np.argmin(np.abs(g["curv"]))) == int(g["order_pf_n_nw"][0])
+    again = util.patch_pca(cloud.to(dev), [p.to(dev) for p in allp])
+    assert torch.equal(again[1], e_d) and torch.equal(again[2], v_d)
+    # eigen-decomposition is one: cov v = lambda v, orthonormal columns
+    for k in (0, 17, 71):
+        x = cloud[allp[k], :3].double()
+        cov = (x - x.mean(0)).T @ (x - x.mean(0)) / x.shape[0]
+        V, L = v_d[k].cpu(), e_d[k].cpu()
+        assert float((cov @ V - V * L[None, :]).abs().max()) < 1e-12 * scale
+        assert float((V.T @ V - torch.eye(3, dtype=torch.float64)).abs().max()) < 1e-12
+
+
+def test_patch_greedy_kernel_equals_the_host_loop(dev):
+    """dnp_patch_greedy against greedy_order_from_interactions on the real W of G6 and on random matrices of
+    every size class (<= 256, 512, 1024, 2048, 4096 patches), ties included."""
+    rng = np.random.default_rng(3)
+    mats = []
+    g = load_golden("G6_patch_propagation")
+    pts = t(g["pc_patchflip"]).to(dev)
+    allp = csr_to_list(g["patch_off"], g["patch_idx"])
+    off, idx, sizes = util.patch_csr(allp, dev)
+    dE = fu._patch_slabs(pts, off, idx, fu._point_patch_ids(idx, sizes, pts.shape[0]), 0, 72, 1e-5)
+    mats.append((fu._interaction_rows(dE, pts, off, idx).cpu().numpy(), 42))
+    for P, start in ((1, 0), (2, 1), (65, 64), (300, 7), (700, 699), (1500, 3), (2500, 11)):
+        mats.append((rng.standard_normal((P, P)) * np.exp(rng.standard_normal((P, 1)) * 3), start))
+    tie = np.round(rng.standard_normal((130, 130)) * 2)              # many exact ties: first maximum must win
+    mats.append((tie, 5))
+    for W, start in mats:
+        o_ref, s_ref, c_ref = fu.greedy_order_from_interactions(W, start)
+        o, sg, c = fu._greedy_on_device(torch.from_numpy(W).to(dev), torch.tensor([start], device=dev))
+        assert np.array_equal(o.cpu().numpy(), o_ref), W.shape
+        assert np.array_equal(sg.cpu().numpy(), s_ref)
+        assert np.array_equal(c.cpu().numpy(), c_ref)                # same fp64 arithmetic, bit for bit
 
 
 @pytest.mark.parametrize("tag", ["500_n", "500_d", "50_n", "50_d"])
@@ -367,10 +428,9 @@ def test_G7_reps_propagation(dev, tag):
     reps = list(zip(csr_to_list(g[f"rep_off_{cap}"], g[f"rep_idx_{cap}"]),
                     csr_to_list(g[f"rest_off_{cap}"], g[f"rest_idx_{cap}"])))
     pts = cloud.clone().to(dev)
-    start = int(g[f"order_{tag}"][0])
-    fu.strongest_field_propagation_reps(pts, [(a.to(dev), b.to(dev)) for a, b in reps], diffuse=(dflag == "d"),
-                                        start_patch=start)
-    tr = fu.strongest_field_propagation_reps.last_trace
+    fu.strongest_field_propagation_reps(pts, [(a.to(dev), b.to(dev)) for a, b in reps], diffuse=(dflag == "d"))
+    tr = fu.last_trace("reps")
+    assert tr["start"] == int(g[f"order_{tag}"][0])                  # the driver's own choice, nothing pinned
     assert np.array_equal(tr["order"], g[f"order_{tag}"])
     assert np.array_equal((tr["sigma"] < 0)[tr["order"]], g[f"flipped_{tag}"])
     assert np.allclose(tr["chosen"], g[f"chosen_{tag}"], rtol=2e-4)
@@ -385,12 +445,12 @@ def test_G8_point_propagation(dev, tag, monkeypatch):
     g = load_golden("G8_point_propagation")
     name, dflag = tag.split("_")
     if tag == "full_n":
-        monkeypatch.setenv("DNP_GREEDY_FORCE_MULTI", "0")           # the single-workgroup form on the full cloud
+        monkeypatch.setattr(fu, "POINT_GREEDY_FORM", 1)              # the single-workgroup form on the full cloud
     cloud = t(g[f"pc_{name}"])
     pts = cloud.clone().to(dev)
     ret = fu.strongest_field_propagation_points(pts, diffuse=(dflag == "d"), starting_point=0)
     assert ret.data_ptr() == pts.data_ptr()
-    order = fu.strongest_field_propagation_points.last_trace["order"].cpu().numpy()
+    order = fu.last_trace("points")["order"]
     ref_order = g[f"order_{tag}"]
     assert sorted(order.tolist()) == list(range(cloud.shape[0]))
     first_diff = int(np.argmax(order != ref_order)) if (order != ref_order).any() else -1
@@ -399,17 +459,17 @@ def test_G8_point_propagation(dev, tag, monkeypatch):
     assert np.array_equal(((out[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g[f"sign_{tag}"])
 
 
-@pytest.mark.parametrize("groups", ["256", "37"])
+@pytest.mark.parametrize("groups", [256, 37])
 def test_G8_multi_workgroup_form_reproduces_the_reference_order(dev, groups, monkeypatch):
-    """The multi-workgroup persistent form (used beyond 12 288 points), forced onto ok.xyz: same 10 000-step
+    """The multi-workgroup persistent form (chosen above 2048 points), pinned explicitly on ok.xyz: same 10 000-step
     visit order and signs as the reference, for two different workgroup counts."""
-    monkeypatch.setenv("DNP_GREEDY_FORCE_MULTI", "1")
-    monkeypatch.setenv("DNP_GREEDY_GROUPS", groups)
+    monkeypatch.setattr(fu, "POINT_GREEDY_FORM", 2)
+    monkeypatch.setattr(fu, "POINT_GREEDY_GROUPS", groups)
     g = load_golden("G8_point_propagation")
     cloud = t(g["pc_full"])
     pts = cloud.clone().to(dev)
     fu.strongest_field_propagation_points(pts, diffuse=True, starting_point=0)
-    order = fu.strongest_field_propagation_points.last_trace["order"].cpu().numpy()
+    order = fu.last_trace("points")["order"]
     assert np.array_equal(order, g["order_full_d"])
     assert np.array_equal(((pts.cpu()[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g["sign_full_d"])
 
@@ -426,13 +486,13 @@ def test_point_propagation_beyond_single_workgroup_capacity(dev):
     scr[flip, 3:] *= -1
     a = scr.clone().to(dev)
     fu.strongest_field_propagation_points(a, diffuse=True)
-    oa = fu.strongest_field_propagation_points.last_trace["order"].cpu()
+    oa = torch.from_numpy(fu.last_trace("points")["order"])
     assert sorted(oa.tolist()) == list(range(20000)) and int(oa[0]) == 0
     agree = ((a.cpu()[:, 3:] * pc[:, 3:]).sum(-1) > 0).float().mean().item()
     assert agree in (0.0, 1.0)
     b = scr.clone().to(dev)
     fu.strongest_field_propagation_points(b, diffuse=True)
-    assert torch.equal(a, b) and torch.equal(oa, fu.strongest_field_propagation_points.last_trace["order"].cpu())
+    assert torch.equal(a, b) and torch.equal(oa, torch.from_numpy(fu.last_trace("points")["order"]))
 
 
 def test_point_propagation_stepwise_fallback_matches_kernel(dev):
@@ -440,7 +500,7 @@ def test_point_propagation_stepwise_fallback_matches_kernel(dev):
     cloud = t(g["pc_sub1000"])[:300].clone()
     a = cloud.clone().to(dev)
     fu.strongest_field_propagation_points(a, diffuse=True)
-    oa = fu.strongest_field_propagation_points.last_trace["order"].cpu().numpy()
+    oa = fu.last_trace("points")["order"]
     b = cloud.clone().to(dev)
     ob = fu._points_stepwise(b, True, 0).cpu().numpy()
     _, oc = O.strongest_field_propagation_points(cloud, diffuse=True)
@@ -492,7 +552,7 @@ def test_sphere100k_256_patches_propagation_recovers_orientation(dev):
     if fu.measure_mean_potential(work) < 0:
         work[:, 3:] *= -1
     assert torch.equal(work[:, 3:], pc[:, 3:])
-    tr = fu.strongest_field_propagation.last_trace
+    tr = fu.last_trace("patches")
     assert sorted(tr["order"].tolist()) == list(range(256))
     s = tr["sigma"][~flip.numpy()]
     assert np.all(tr["sigma"][flip.numpy()] == -s[0]) and np.all(s == s[0])
@@ -533,8 +593,8 @@ def test_fuzz_shapes_strides_gathers_against_oracle(dev):
         nbytes = lib.dnp_field_grad_workspace_bytes(S, T, max_pts)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         rc = lib.dnp_field_grad_f32(_lib.ptr(d_src), S, ld_s, _lib.ptr(d_si), _lib.ptr(d_tgt), T, ld_t, _lib.ptr(d_ti),
-                                    eps, max_pts, _lib.ptr(d_out), 3, int(scatter), int(accumulate), _lib.ptr(ws), nbytes,
-                                    _lib.current_stream())
+                                    eps, max_pts, _lib.ptr(d_out), 3, int(scatter), int(accumulate), None, _lib.ptr(ws),
+                                    nbytes, _lib.current_stream())
         assert rc == 0, (case, lib.dnp_last_error())
         torch.cuda.synchronize()
         out = d_out.cpu()
@@ -557,15 +617,16 @@ def test_G13_hand_point_and_patch_propagation(dev):
     cloud = t(g["pc_scrambled"])
     pts = cloud.clone().to(dev)
     fu.strongest_field_propagation_points(pts, diffuse=True, starting_point=17)
-    order = fu.strongest_field_propagation_points.last_trace["order"].cpu().numpy()
+    order = fu.last_trace("points")["order"]
     assert np.array_equal(order, g["order_points"])                           # all 10 000 steps
     assert np.array_equal(((pts.cpu()[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g["sign_points"])
     pc_patch = t(g["pc_patchflip"])
     allp = csr_to_list(g["patch_off"], g["patch_idx"])
     work = pc_patch.clone().to(dev)
     fu.strongest_field_propagation(work, [(i, p.to(dev)) for i, p in enumerate(allp)], [p.to(dev) for p in allp],
-                                   diffuse=True, start_patch=int(g["order_patch"][0]))
-    tr = fu.strongest_field_propagation.last_trace
+                                   diffuse=True)
+    tr = fu.last_trace("patches")
+    assert tr["start"] == int(g["order_patch"][0])                   # default start patch = the reference's
     assert np.array_equal(tr["order"], g["order_patch"])
     assert np.array_equal((tr["sigma"] < 0)[tr["order"]], g["flipped_patch"])
     assert np.allclose(tr["chosen"], g["chosen_patch"], rtol=2e-4)
@@ -575,9 +636,9 @@ def test_G13_hand_point_and_patch_propagation(dev):
 # ---- float64 clouds through the per-point driver (the socket path) -----------------------------------------
 @pytest.mark.parametrize("tag", ["sub1000_n", "sub1000_d", "sub3000_n", "sub3000_d"])
 def test_G14_float64_cloud_point_propagation(dev, tag):
-    """The reference propagates a float64 cloud in fp64 (util.npxyz2tensor feeds float64).  The persistent kernel
-    evaluates in fp32 whatever the input dtype; on the goldens it reproduces the reference's fp64 visit order and
-    signs, returns float64, and only ever multiplies normals by +-1 (so the float64 payload stays exact)."""
+    """The reference propagates a float64 cloud in fp64 (util.npxyz2tensor feeds float64) and so does
+    dnp_point_greedy_f64: the reference's fp64 visit order and signs, float64 out, and normals only ever
+    multiplied by +-1 (the float64 payload stays exact)."""
     g = load_golden("G14_point_propagation_f64")
     name, dflag = tag.split("_")
     cloud = t(g[f"pc_{name}"])
@@ -585,7 +646,7 @@ def test_G14_float64_cloud_point_propagation(dev, tag):
     pts = cloud.clone().to(dev)
     out = fu.strongest_field_propagation_points(pts, diffuse=(dflag == "d"), starting_point=0)
     assert out.dtype == torch.float64 and out.data_ptr() == pts.data_ptr()
-    order = fu.strongest_field_propagation_points.last_trace["order"].cpu().numpy()
+    order = fu.last_trace("points")["order"]
     assert np.array_equal(order, g[f"order_{tag}"])
     res = pts.cpu()
     assert np.array_equal(((res[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g[f"sign_{tag}"])
@@ -604,10 +665,86 @@ def test_point_propagation_multi_workgroup_two_points_per_lane(dev):
     scr[torch.rand(140000, generator=gen) < 0.3, 3:] *= -1
     a = scr.clone().to(dev)
     fu.strongest_field_propagation_points(a, diffuse=True, starting_point=4242)
-    oa = fu.strongest_field_propagation_points.last_trace["order"].cpu()
+    oa = torch.from_numpy(fu.last_trace("points")["order"])
     assert int(oa[0]) == 4242 and torch.equal(torch.sort(oa).values, torch.arange(140000))
     agree = ((a.cpu()[:, 3:] * pc[:, 3:]).sum(-1) > 0).float().mean().item()
     assert agree in (0.0, 1.0)
     b = scr.clone().to(dev)
     fu.strongest_field_propagation_points(b, diffuse=True, starting_point=4242)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("form", [0, 1, 2])
+def test_G16_float64_full_ok_cloud(dev, form, monkeypatch):
+    """The FULL 10 000-point ok.xyz as a float64 cloud (what the socket path feeds, util.py:71-77): all 10 000
+    steps of the reference's fp64 visit order and every final sign, with the form chosen by the library (one
+    workgroup per CU), with 37 workgroups, and - on the first 4096 points, its capacity in fp64 - the
+    single-workgroup form against the multi-workgroup one."""
+    g8, g16 = load_golden("G8_point_propagation"), load_golden("G16_point_propagation_f64_full")
+    cloud = t(g8["pc_full"]).double()
+    if form == 1:
+        sub = cloud[:4096].clone()
+        monkeypatch.setattr(fu, "POINT_GREEDY_FORM", 1)
+        a = sub.clone().to(dev)
+        fu.strongest_field_propagation_points(a, diffuse=True)
+        oa = fu.last_trace("points")["order"]
+        monkeypatch.setattr(fu, "POINT_GREEDY_FORM", 2)
+        b = sub.clone().to(dev)
+        fu.strongest_field_propagation_points(b, diffuse=True)
+        assert np.array_equal(oa, fu.last_trace("points")["order"]) and torch.equal(a, b)
+        return
+    monkeypatch.setattr(fu, "POINT_GREEDY_FORM", form)
+    if form == 2:
+        monkeypatch.setattr(fu, "POINT_GREEDY_GROUPS", 37)
+    pts = cloud.clone().to(dev)
+    out = fu.strongest_field_propagation_points(pts, diffuse=True, starting_point=0)
+    assert out.dtype == torch.float64 and out.data_ptr() == pts.data_ptr()
+    order = fu.last_trace("points")["order"]
+    ref = g16["order_full_d"].astype(np.int64)
+    first_diff = int(np.argmax(order != ref)) if (order != ref).any() else -1
+    assert first_diff == -1, f"fp64 visit order diverges from the reference at step {first_diff}"
+    res = pts.cpu()
+    assert np.array_equal(((res[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g16["sign_full_d"])
+
+
+def test_point_greedy_never_reads_a_rewritten_normal(dev):
+    """Regression for the last-step race: the kernels leave pts untouched until a stream-ordered copy, so the last
+    chosen point's field enters everybody's E with the sign decided for it.  E_out of the persistent kernel must
+    equal the step-wise evaluation (which has no concurrency at all) bit for bit, in both forms."""
+    lib = _lib.require_device()
+    g = load_golden("G8_point_propagation")
+    cloud = t(g["pc_sub1000"]).to(dev)
+    ref = cloud.clone()
+    fu._points_stepwise(ref, True, 0)
+    for form, groups in ((1, 0), (2, 0), (2, 3)):
+        work = cloud.clone()
+        N = work.shape[0]
+        order = torch.empty(N, dtype=torch.int64, device=dev)
+        nbytes = lib.dnp_point_greedy_workspace_bytes(N, 4)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        rc = lib.dnp_point_greedy_f32(_lib.ptr(work), N, 6, 0, 1e-6, 1, _lib.ptr(order), None, form, groups,
+                                      _lib.ptr(ws), nbytes, _lib.current_stream())
+        assert rc == 0, lib.dnp_last_error()
+        torch.cuda.synchronize()
+        assert int(ws[:4].view(torch.int32).item()) == 0
+        assert torch.equal(work, ref), (form, groups)
+
+
+def test_nonfinite_leaf_components_are_counted_and_zeroed(dev, capsys):
+    """field_utils.py:110-115: Inf/NaN leaf components are reported ("warning: %d inf in field_grad") and zeroed.
+    A source at 1e30 overflows fp32 in the squared distance -> NaN in that leaf only; with 15000-row leaves the
+    other leaf still contributes."""
+    gen = torch.Generator().manual_seed(4)
+    src = torch.rand(16000, 6, generator=gen) - 0.5
+    src[3, :3] = 1e30                                  # in the first leaf (rows 0..7999)
+    tgt = torch.rand(40, 3, generator=gen) - 0.5
+    E = fu.field_grad(src.to(dev), tgt.to(dev))
+    ref = O.field_grad(src, tgt)
+    fu.flush_warnings()
+    printed = capsys.readouterr().out
+    assert "nan in field_grad" in printed or "inf in field_grad" in printed
+    assert bool(torch.isfinite(E).all())
+    assert rel_rowwise(E.cpu(), ref) < 1e-4            # the surviving leaf, as in the reference
+    fu.field_grad(src[8000:].to(dev), tgt.to(dev))     # a clean call prints nothing
+    fu.flush_warnings()
+    assert "field_grad" not in capsys.readouterr().out

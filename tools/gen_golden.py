@@ -170,9 +170,18 @@ def _run_patch_driver(fu, util, which, pc0, patches_arg, all_arg, diffuse, weigh
     calls, inter = [], []
     orig_fg, orig_torch = fu.field_grad, fu.torch
 
+    depth = [0]
+
     def rec_fg(sources, means, *a, **k):
-        calls.append((sources.shape[0], means.shape[0], sources[0, :3].clone(), sources[0, 3:].clone()))
-        return orig_fg(sources, means, *a, **k)
+        # the reference's recursion (field_utils.py:73-94) re-enters through the module global: record only
+        # the drivers' own calls
+        if depth[0] == 0:
+            calls.append((sources.shape[0], means.shape[0], sources[0, :3].clone(), sources[0, 3:].clone()))
+        depth[0] += 1
+        try:
+            return orig_fg(sources, means, *a, **k)
+        finally:
+            depth[0] -= 1
 
     fu.field_grad = rec_fg
     fu.torch = _TorchProxy(inter)
@@ -504,6 +513,163 @@ def g14(fu, util):
     save("G14_point_propagation_f64", **out)
 
 
+def pca_normals_numpy(xyz, k):
+    """Unoriented PCA normals (own numpy routine, NOT the reference's open3d estimator, which is absent
+    offline): eigenvector of the smallest eigenvalue of the covariance of the k nearest neighbours
+    (scipy cKDTree, the point itself included), fp64, sign as numpy.linalg.eigh returns it."""
+    from scipy.spatial import cKDTree
+    x = np.asarray(xyz, dtype=np.float64)
+    _, nn = cKDTree(x).query(x, k=k)
+    nb = x[nn]                                              # [N, k, 3]
+    rel = nb - nb.mean(axis=1, keepdims=True)
+    cov = np.einsum("nki,nkj->nij", rel, rel) / k
+    _, v = np.linalg.eigh(cov)
+    return v[:, :, 0]
+
+
+def g15(fu, util):
+    """BASELINE config 3 on a cloud the reference holds (data/boxunion.xyz stands in for the
+    missing lion.xyz) with the flags of demos/lion.sh:13-19: the stages of orient_large.py:18-75 run with the
+    reference's own functions - Transform, _divide_pc + merge_nodes (n_part 41, min 100), fix_n_filter
+    (curvature_threshold 0.0), orient_center, torch.manual_seed(1) randperm representatives (cap 500),
+    strongest_field_propagation_reps(diffuse=True), measure_mean_potential.  Normals come from
+    pca_normals_numpy (k = 50, lion.sh --n 50); the PointCNN vote is skipped (models absent offline)."""
+    import inference_utils_shim as iu
+    raw = util.xyz2tensor(open(f"{REF}/data/boxunion.xyz").read(), append_normals=False)
+    pc3, tr = util.Transform.trans(raw)
+    t0 = time.time()
+    nrm = torch.from_numpy(pca_normals_numpy(pc3.numpy(), 50)).float()
+    pc = torch.cat([pc3, nrm], dim=1).contiguous()
+    print(f"  normals: {time.time() - t0:.1f}s")
+    t0 = time.time()
+    allp = ref_patches(util, pc, 41, 100)
+    print(f"  reference partition + merge: {len(allp)} patches, {time.time() - t0:.1f}s")
+    pc_in = pc.clone()
+    kept = iu.fix_n_filter(pc_in, [p.clone() for p in allp], 0.0)
+    for _, p in kept:
+        pc_in[p] = util.orient_center(pc_in[p])
+    print(f"  kept {len(kept)}/{len(allp)}")
+    torch.manual_seed(1)
+    reps = []
+    for p in allp:
+        perm = torch.randperm(p.shape[0])
+        reps.append((p[perm[:500]], p[perm[500:]]))
+    t0 = time.time()
+    pts, calls, inter = _run_patch_driver(fu, util, "reps", pc_in, reps, None, True, None)
+    print(f"  reference reps propagation: {time.time() - t0:.1f}s")
+    firsts = [(int(r[0]), pc_in[int(r[0]), :3]) for r, _ in reps]
+    mins = [(int(r.min()), pc_in[int(r.min()), :3]) for r, _ in reps]
+    order, flipped = _order_from_calls(calls[:len(allp)], pc_in, firsts, mins)
+    mean_phi = fu.measure_mean_potential(pts)
+    i32 = lambda t: torch.as_tensor(t).to(torch.int32)
+    save("G15_boxunion_config3",
+         pc=pc, center=tr.center, scale=tr.scale,
+         patch_off=np.cumsum([0] + [len(p) for p in allp]), patch_idx=i32(torch.cat(allp)),
+         kept=np.array([i for i, _ in kept]),
+         prefilter_sign=((pc_in[:, 3:] * pc[:, 3:]).sum(-1) > 0),          # cloud handed to the propagation
+         rep_off=np.cumsum([0] + [len(r) for r, _ in reps]), rep_idx=i32(torch.cat([r for r, _ in reps])),
+         rest_off=np.cumsum([0] + [len(r) for _, r in reps]), rest_idx=i32(torch.cat([r for _, r in reps])),
+         curv=np.array([util.pca_eigen_values(pc_in[r])[0].item() for r, _ in reps]),
+         order=order, flipped=flipped, chosen=np.array([float(t[t.abs().argmax()]) for t in inter]),
+         sign=((pts[:, 3:] * pc_in[:, 3:]).sum(-1) > 0), mean_potential=mean_phi)
+
+
+def g16(fu, util):
+    """Per-point propagation of the FULL 10 000-point ok.xyz as a float64 cloud (the socket path,
+    util.py:71-77 -> field_utils.py:353-388 in fp64): complete visit order + final signs."""
+    base = np.load(os.path.join(OUT, "G8_point_propagation.npz"))
+    cloud = torch.from_numpy(base["pc_full"]).double()
+    out = {}
+    for diffuse in (True,):
+        order = []
+        orig_fg = fu.field_grad
+
+        def rec_fg(sources, means, *a, **k):
+            order.append(sources.storage_offset() // 6)
+            return orig_fg(sources, means, *a, **k)
+
+        fu.field_grad = rec_fg
+        t0 = time.time()
+        try:
+            pts = fu.strongest_field_propagation_points(cloud.clone(), diffuse=diffuse, starting_point=0)
+        finally:
+            fu.field_grad = orig_fg
+        assert pts.dtype == torch.float64
+        out["order_full_d"] = np.array(order).astype(np.int32)
+        out["sign_full_d"] = ((pts[:, 3:] * cloud[:, 3:]).sum(-1) > 0)
+        print(f"  G16 full fp64 per-point: {time.time() - t0:.1f}s")
+    save("G16_point_propagation_f64_full", **out)      # the cloud itself is G8's pc_full cast to float64
+
+
+def gw(fu, util):
+    """Byte-level vectors of the socket wire format (socket_server_para.py:137-195): the reference's own
+    handle_client is driven through a fake connection object; the estimator it would call is replaced by a
+    stub that records the decoded request and returns a fixed array, so the fixture pins the framing (header
+    parse, ack, payload decode, reply encode, the ERROR reply), not an estimator."""
+    import json
+    import tempfile
+    sys.modules.setdefault("graph_dipole", types.ModuleType("graph_dipole"))
+    cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp())                 # log_msg appends to ./error.log
+    try:
+        import socket_server_para as srv
+    finally:
+        pass
+
+    class FakeConn:
+        def __init__(self, chunks):
+            self.chunks, self.sent = list(chunks), []
+
+        def recv(self, n):
+            if not self.chunks:
+                return b""
+            c = self.chunks[0]
+            out, rest = c[:n], c[n:]
+            if rest:
+                self.chunks[0] = rest
+            else:
+                self.chunks.pop(0)
+            return out
+
+        def sendall(self, b):
+            self.sent.append(bytes(b))
+
+        def close(self):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    g = np.random.default_rng(5)
+    xyz = g.standard_normal((7, 3))
+    result = np.concatenate([xyz.astype(np.float32), g.standard_normal((7, 3)).astype(np.float32)], axis=1)
+    seen = {}
+
+    def stub(xyz_data, config):
+        seen["xyz"], seen["config"] = np.array(xyz_data), dict(config)
+        return result
+
+    srv.simple_estimate = stub
+    header = json.dumps({"function_name": "simple_estimate", "function_config": {"diffuse": True}, "data_size": 7}).encode()
+    payload = xyz.astype(np.float64).tobytes()
+    ok = FakeConn([header, payload[:50], payload[50:]])        # payload arriving in two pieces
+    srv.handle_client(ok, ("test", 0))
+    bad_fn = FakeConn([json.dumps({"function_name": "nope", "function_config": {}, "data_size": 7}).encode(), payload])
+    srv.handle_client(bad_fn, ("test", 0))
+    short = FakeConn([header, payload[:100]])                      # connection drops early: size mismatch
+    srv.handle_client(short, ("test", 0))
+    os.chdir(cwd)
+    u8 = lambda b: np.frombuffer(b, dtype=np.uint8)
+    assert np.array_equal(seen["xyz"], xyz) and seen["config"] == {"diffuse": True}
+    save("GW_wire_format", header=u8(header), payload=u8(payload), xyz=xyz, result=result,
+         ack=u8(ok.sent[0]), reply=u8(ok.sent[1]), n_sent_ok=len(ok.sent),
+         unknown_ack=u8(bad_fn.sent[0]), unknown_reply=u8(bad_fn.sent[1]),
+         short_ack=u8(short.sent[0]), short_reply=u8(short.sent[1]), decoded_xyz=seen["xyz"])
+
+
 def make_inference_shim():
     """inference_utils.py imports models/ (torch_geometric, absent offline) at module level.
     Only its pure-torch fix_n_filter is on the path; load that one function's source object by
@@ -519,13 +685,14 @@ def make_inference_shim():
     spec.loader.exec_module(mod)
 
 
-ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13, G14=g14)
+ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13, G14=g14, G15=g15, G16=g16, GW=gw)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
+    ap.add_argument("--threads", type=int, default=os.cpu_count())
     args = ap.parse_args()
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(args.threads)
     sys.path.insert(0, REF)
     for name in ("open3d", "pymeshlab", "gurobipy"):
         sys.modules.setdefault(name, types.ModuleType(name))

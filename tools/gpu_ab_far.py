@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""A/B of the far-field (one-transcendental) path of pair_kernel on the bench workload (100k sphere, 256 patches,
+cloud sorted by patch): the product library against a build with -DDNP_FAR=0, interleaved launches in ONE process
+on ONE device (cdna guide rule 24), plus the accuracy of both against the fp64 oracle on a row sample.
+
+    python tools/gpu_ab_far.py            (on the GPU box; builds tools/bin/libdnp_nofar.so first if missing)
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import fibonacci_patches, sphere_cloud  # noqa: E402
+from dipole_normal_prop_amd import _lib, build, util  # noqa: E402
+from oracle import c_oracle  # noqa: E402
+
+NOFAR = os.path.join(ROOT, "tools", "bin", "libdnp_nofar.so")
+
+
+def bind(path):
+    lib = ctypes.CDLL(path)
+    res, args = _lib.SIGNATURES["dnp_patch_fields_f32"]
+    lib.dnp_patch_fields_f32.restype, lib.dnp_patch_fields_f32.argtypes = res, args
+    return lib
+
+
+def main():
+    if not os.path.exists(NOFAR):
+        build.build(extra_flags=["-DDNP_FAR=0"], out=NOFAR, verbose=False)
+    build.build(verbose=False)
+    libs = {"far": bind(build.LIB), "exact": bind(NOFAR)}
+    dev = torch.device("cuda:0")
+    pc = sphere_cloud()
+    patches = fibonacci_patches(pc)
+    off, idx, sizes = util.patch_csr(patches, dev)
+    pts = pc.to(dev)[idx].contiguous()
+    N, P = pts.shape[0], len(sizes)
+    point_patch = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
+    dE = {k: torch.empty((P, N, 3), dtype=torch.float32, device=dev) for k in libs}
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def launch(name):
+        rc = libs[name].dnp_patch_fields_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch), 0, P,
+                                             1e-5, _lib.ptr(dE[name]), stream)
+        assert rc == 0
+
+    for name in libs:
+        for _ in range(3):
+            launch(name)
+    torch.cuda.synchronize()
+    times = {k: [] for k in libs}
+    for rnd in range(24):
+        for name in (("far", "exact") if rnd % 2 == 0 else ("exact", "far")):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            launch(name)
+            b.record()
+            torch.cuda.synchronize()
+            times[name].append(a.elapsed_time(b))
+    for name, ts in times.items():
+        ts = np.array(ts)
+        print(f"{name:6s} median {np.median(ts):.3f} ms  min {ts.min():.3f}  max {ts.max():.3f}  "
+              f"({1e10 / np.median(ts) / 1e9:.3f} Tpairs/s, roofline frac {33e10 / (np.median(ts) * 1e-3) / 157.3e12:.3f})")
+    print(f"far / exact = {np.median(times['far']) / np.median(times['exact']):.4f}")
+
+    # accuracy on a row sample: summed field of all patches (= all-pairs field minus the own-patch part) vs fp64
+    rows = np.arange(0, N, 997)
+    cpu = pts.cpu().numpy()
+    pp = point_patch.cpu().numpy()
+    for name in libs:
+        tot = dE[name][:, rows].double().sum(dim=0).cpu().numpy()
+        ref = np.zeros_like(tot)
+        for i, r in enumerate(rows):
+            others = cpu[pp != pp[r]]
+            ref[i] = c_oracle.field_grad_f64(others, cpu[r:r + 1])[0]
+        err = np.linalg.norm(tot - ref, axis=1) / np.linalg.norm(ref, axis=1)
+        print(f"{name:6s} summed slabs vs fp64 oracle on {len(rows)} rows: median {np.median(err):.2e}  max {err.max():.2e}")
+    # per-slab comparison far vs exact: one far patch and the nearest ones
+    d = (dE["far"] - dE["exact"]).double().norm(dim=-1)
+    n = dE["exact"].double().norm(dim=-1).clamp(min=1e-300)
+    rel = (d / n)
+    print(f"far vs exact per slab row: max rel {float(rel.max()):.2e}, mean {float(rel.mean()):.2e}; "
+          f"fraction of slab rows bitwise equal {float((d == 0).double().mean()):.3f}")
+
+
+if __name__ == "__main__":
+    main()

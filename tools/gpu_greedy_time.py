@@ -20,12 +20,18 @@ def run(pc, label):
     print(f"{label}: N={n} {dt*1e3:.1f} ms -> {dt/n*1e6:.2f} us/step, {n*n/dt/1e9:.2f} Gpairs/s", flush=True)
 
 ok = torch.from_numpy(load_golden("G8_point_propagation")["pc_full"])
-run(ok, "ok.xyz single-workgroup")
-os.environ["DNP_GREEDY_FORCE_MULTI"] = "1"
-run(ok, "ok.xyz multi-workgroup ")
-del os.environ["DNP_GREEDY_FORCE_MULTI"]
-run(sphere(30000), "sphere multi-workgroup")
-run(sphere(100000), "sphere multi-workgroup")
+fu.POINT_GREEDY_FORM = 1
+run(ok, "ok.xyz fp32 single-workgroup")
+fu.POINT_GREEDY_FORM = 2
+run(ok, "ok.xyz fp32 multi-workgroup ")
+run(ok.double(), "ok.xyz fp64 multi-workgroup ")
+fu.POINT_GREEDY_FORM = 1
+run(ok.double()[:4096], "ok.xyz[:4096] fp64 single-workgroup")
+fu.POINT_GREEDY_FORM = 0
+run(ok[:2000], "ok.xyz[:2000] fp32 auto")
+run(sphere(30000), "sphere fp32 multi-workgroup")
+run(sphere(100000), "sphere fp32 multi-workgroup")
+run(sphere(100000).double(), "sphere fp64 multi-workgroup")
 b = ok[:2000].clone().to(dev)
 t0 = time.perf_counter(); fu._points_stepwise(b, True, 0); torch.cuda.synchronize()
 print(f"step-wise fallback: N=2000 {(time.perf_counter()-t0)*1e3:.1f} ms -> {(time.perf_counter()-t0)/2000*1e6:.1f} us/step")

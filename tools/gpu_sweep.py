@@ -3,6 +3,7 @@
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from dipole_normal_prop_amd import field_utils as fu
 from tools.gpu_check import sphere
 
@@ -15,7 +16,12 @@ def timeit(fn, reps=20):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps
 
+import numpy as np
+from conftest import load_golden
 grid = fu.util.gen_grid().to(dev)
+fd = torch.from_numpy(load_golden("G5_fandisk_allpairs")["pc"]).to(dev)
+t = timeit(lambda: fu.field_grad(fd, fd), reps=50)
+print(f"fandisk all-pairs (config 2): {t*1e6:.1f} us ({fd.shape[0]**2/t/1e9:.1f} Gpairs/s)", flush=True)
 for n in (1000, 3000, 11031, 30000, 100000):
     pc = sphere(n).to(dev)
     t = timeit(lambda: fu.field_grad(pc, pc), reps=20 if n < 50000 else 5)
