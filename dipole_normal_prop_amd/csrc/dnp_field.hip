@@ -5,6 +5,8 @@
 // pair_kernel over (target tiles x chunks) and then reduce_kernel, which sums the chunks of
 // each leaf in fp64, zeroes non-finite leaf components (field_utils.py:110-115 / :53-54) and
 // adds the leaves.
+#include <math.h>
+
 #include <algorithm>
 #include <utility>
 #include <vector>
@@ -20,11 +22,14 @@ namespace dnp {
 #define DNP_MINCHUNK_CAP 512
 #endif
 static inline int64_t min_chunk(int64_t S) { const int64_t m = S / 64; return m < 64 ? 64 : (m > DNP_MINCHUNK_CAP ? DNP_MINCHUNK_CAP : m); }
-constexpr int kKTLarge = 4;                // targets per lane for large target sets (swept: 4 x 2 accumulator sets)
+// targets per lane for large target sets: 2 in the scalar-unit kernel (contiguous sources), 4 in the LDS kernel
+// (gathered sources; swept: 4 x 2 accumulator sets); 1 for small target sets in both
+constexpr int kKTScalar = 2, kKTLds = 4;
 constexpr int64_t kTilesForLarge = 64;     // ... used once that still leaves >= 64 target tiles
 constexpr size_t kSlabCap = (size_t)1 << 30;  // bytes of partial slab per round
-// workgroups of 256 threads a CU holds at once: KT = 4 needs 134 VGPRs (3 waves per SIMD), KT = 1 fits 8
-constexpr int kResidentLarge = 3, kResidentSmall = 8;
+// workgroups of 256 threads a CU holds at once: the LDS kernel at KT = 4 needs 134 VGPRs (3 waves per SIMD);
+// KT = 1 and the scalar kernel (57 VGPRs at KT = 2) fit 8
+constexpr int kResidentLds4 = 3, kResidentFull = 8;
 
 struct Plan {
     // one entry per round; every round is a run of whole leaves
@@ -67,7 +72,7 @@ static int compute_units() {
 // runs in ceil(blocks / resident) rounds of equal length: pick the chunk count that wastes the least of the last
 // round while keeping the fp64 partial slab (24 B per target and chunk, written once and read once) small.
 static int64_t choose_chunks(int64_t S, int64_t T, int64_t t_tiles, int kt, int64_t n_leaves, int64_t cap) {
-    const int64_t slots = (int64_t)compute_units() * (kt == kKTLarge ? kResidentLarge : kResidentSmall);
+    const int64_t slots = (int64_t)compute_units() * (kt == kKTLds ? kResidentLds4 : kResidentFull);
     const int64_t longest = S / min_chunk(S) > 0 ? S / min_chunk(S) : 1;   // most chunks the minimum length allows
     int64_t hi = cap < longest ? cap : longest;
     if (hi < n_leaves) hi = n_leaves;
@@ -87,12 +92,13 @@ static int64_t choose_chunks(int64_t S, int64_t T, int64_t t_tiles, int kt, int6
     return best;
 }
 
-static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem) {
+static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem, bool scalar_kernel) {
     Plan plan;
+    const int kKTLarge = scalar_kernel ? kKTScalar : kKTLds;
     std::vector<int64_t> cuts;  // leaf end offsets
     if (S > 0) split_leaves(0, S, max_pts, cuts);
     // small problems are latency bound: prefer many short workgroups (1 target per lane, chunks down to 64
-    // sources); large ones amortise the LDS reads over 4 targets per lane
+    // sources); large ones amortise the source fetch over 2 (scalar kernel) / 4 (LDS kernel) targets per lane
     plan.kt = (T >= (int64_t)kBlock * kKTLarge * kTilesForLarge) ? kKTLarge : 1;
     const int64_t t_tiles = ceil_div(T > 0 ? T : 1, (int64_t)kBlock * plan.kt);
     const int64_t n_leaves = (int64_t)cuts.size();
@@ -232,7 +238,9 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
         return DNP_OK;
     }
 
-    const Plan plan = make_plan(S, T, max_pts, NC, sizeof(double));
+    // contiguous source rows go through the scalar unit, gathered rows through LDS (pair_kernel.h)
+    const bool scalar_kernel = (src_idx == nullptr);
+    const Plan plan = make_plan(S, T, max_pts, NC, sizeof(double), scalar_kernel);
     const size_t need = plan_workspace(plan, T, NC, sizeof(double));
     if (!workspace || workspace_bytes < need) {
         set_error("workspace of %zu bytes required, %zu given", need, workspace ? workspace_bytes : (size_t)0);
@@ -252,22 +260,36 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
         // one chunk that is also the only leaf of the only round: the pair kernel writes the final rows
         const bool direct = plan.rounds.size() == 1 && n_chunks == 1;
         pa.out = direct ? out : nullptr; pa.ld_out = ld_out; pa.out_scatter = out_scatter; pa.accumulate = accumulate;
-        pa.nonfinite = nonfinite; pa.far_d2 = F(0);
+        pa.nonfinite = nonfinite;
+        pa.far_d2 = eps > F(0) ? (F)pow((double)eps / kFarRatio, 2.0 / 3.0) : F(0);
         for (int i = 0; i <= n_chunks; ++i) pa.chunk_off[i] = r.chunk_off[i];
         const dim3 grid((unsigned)t_tiles, (unsigned)n_chunks);
         // eps > 0 (what every caller of the reference passes): the short chain; otherwise the explicit one
         const int variant = (MODE != kField) ? kFast : (eps > F(0) ? kFast : (eps == F(0) ? kNanCoinc : kRobust));
 #define DNP_LAUNCH_PAIR(KT, V) \
     hipLaunchKernelGGL((pair_kernel<F, double, MODE, KT, V>), grid, dim3(kBlock), 0, stream, pa)
-        if (plan.kt == kKTLarge) {
-            if (variant == kFast) DNP_LAUNCH_PAIR(kKTLarge, kFast);
-            else if (variant == kNanCoinc) DNP_LAUNCH_PAIR(kKTLarge, kNanCoinc);
-            else DNP_LAUNCH_PAIR(kKTLarge, kRobust);
+#define DNP_LAUNCH_SCALAR(KT, V) \
+    hipLaunchKernelGGL((pair_kernel_scalar<F, double, MODE, KT, V, (sizeof(F) == 4)>), grid, dim3(kBlock), 0, stream, pa)
+        if (scalar_kernel) {
+            if (plan.kt == kKTScalar) {
+                if (variant == kFast) DNP_LAUNCH_SCALAR(kKTScalar, kFast);
+                else if (variant == kNanCoinc) DNP_LAUNCH_SCALAR(kKTScalar, kNanCoinc);
+                else DNP_LAUNCH_SCALAR(kKTScalar, kRobust);
+            } else {
+                if (variant == kFast) DNP_LAUNCH_SCALAR(1, kFast);
+                else if (variant == kNanCoinc) DNP_LAUNCH_SCALAR(1, kNanCoinc);
+                else DNP_LAUNCH_SCALAR(1, kRobust);
+            }
+        } else if (plan.kt == kKTLds) {
+            if (variant == kFast) DNP_LAUNCH_PAIR(kKTLds, kFast);
+            else if (variant == kNanCoinc) DNP_LAUNCH_PAIR(kKTLds, kNanCoinc);
+            else DNP_LAUNCH_PAIR(kKTLds, kRobust);
         } else {
             if (variant == kFast) DNP_LAUNCH_PAIR(1, kFast);
             else if (variant == kNanCoinc) DNP_LAUNCH_PAIR(1, kNanCoinc);
             else DNP_LAUNCH_PAIR(1, kRobust);
         }
+#undef DNP_LAUNCH_SCALAR
 #undef DNP_LAUNCH_PAIR
         DNP_CHECK_HIP(hipGetLastError());
         if (direct) break;
@@ -293,13 +315,17 @@ extern "C" {
 
 size_t dnp_field_grad_workspace_bytes(int64_t S, int64_t T, int64_t max_pts) {
     if (S <= 0 || T <= 0) return 256;
-    // chunk sums are kept in fp64 for both precisions
-    return plan_workspace(make_plan(S, T, max_pts, 3, sizeof(double)), T, 3, sizeof(double));
+    // chunk sums are kept in fp64 for both precisions; the answer covers both kernels (with / without src_idx)
+    const size_t a = plan_workspace(make_plan(S, T, max_pts, 3, sizeof(double), true), T, 3, sizeof(double));
+    const size_t b = plan_workspace(make_plan(S, T, max_pts, 3, sizeof(double), false), T, 3, sizeof(double));
+    return a > b ? a : b;
 }
 
 size_t dnp_potential_workspace_bytes(int64_t S, int64_t T, int64_t max_pts) {
     if (S <= 0 || T <= 0) return 256;
-    return plan_workspace(make_plan(S, T, max_pts, 1, sizeof(double)), T, 1, sizeof(double));
+    const size_t a = plan_workspace(make_plan(S, T, max_pts, 1, sizeof(double), true), T, 1, sizeof(double));
+    const size_t b = plan_workspace(make_plan(S, T, max_pts, 1, sizeof(double), false), T, 1, sizeof(double));
+    return a > b ? a : b;
 }
 
 int dnp_field_grad_f32(const float* src, int64_t S, int64_t ld_src, const int64_t* src_idx,

@@ -11,9 +11,10 @@ namespace dnp {
 #ifndef DNP_KT
 #define DNP_KT 4
 #endif
-constexpr int kPatchKT = DNP_KT;
-// far-field (one transcendental) path for tiles whose sources are far from the wave's targets; the drivers sort
-// the cloud by patch, so both are spatially coherent runs
+constexpr int kPatchKT = DNP_KT;          // LDS kernel (gathered patches)
+constexpr int kPatchScalarKT = 2;         // scalar kernel (patch-sorted cloud): 57 VGPRs, 8 waves per SIMD
+// far-field (one transcendental) chain for (wave, patch) combinations whose boxes are far apart; the drivers sort
+// the cloud by patch, so a wave's 128 consecutive targets and a patch's sources are both spatially compact
 #ifndef DNP_FAR
 #define DNP_FAR 1
 #endif
@@ -89,15 +90,27 @@ int dnp_patch_fields_f32(const float* pts, int64_t N, int64_t ld_pts, const int6
         pa.chunk_off_dev = patch_off; pa.chunk_base = p_begin + k0; pa.tgt_group = point_patch;
         pa.eps = eps; pa.partial = dE + k0 * N * 3;
         pa.far_d2 = eps > 0.f ? (float)pow((double)eps / kFarRatio, 2.0 / 3.0) : 0.f;
-        const dim3 grid((unsigned)t_tiles, (unsigned)kn);
+#ifdef DNP_FAR_D2   // timing experiments only: force the far test (1e30f = never far, -1.f = always far)
+        pa.far_d2 = DNP_FAR_D2;
+#endif
         const hipStream_t st = (hipStream_t)stream;
-        if (eps > 0.f)
-            hipLaunchKernelGGL((pair_kernel<float, float, kField, kPatchKT, kFast, kPatchFar>), grid, dim3(kBlock), 0, st,
-                               pa);
-        else if (eps == 0.f)
-            hipLaunchKernelGGL((pair_kernel<float, float, kField, kPatchKT, kNanCoinc>), grid, dim3(kBlock), 0, st, pa);
-        else
-            hipLaunchKernelGGL((pair_kernel<float, float, kField, kPatchKT, kRobust>), grid, dim3(kBlock), 0, st, pa);
+#ifndef DNP_FORCE_LDS   // A/B builds only (tools/gpu_ab_far.py): 1 sends the sorted layout through the LDS kernel too
+#define DNP_FORCE_LDS 0
+#endif
+        if (!patch_idx && eps > 0.f && !DNP_FORCE_LDS) {
+            // patch-sorted cloud (what the drivers pass): contiguous sources -> the scalar-unit kernel
+            const dim3 sgrid((unsigned)ceil_div(N, (int64_t)kBlock * kPatchScalarKT), (unsigned)kn);
+            hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar>), sgrid,
+                               dim3(kBlock), 0, st, pa);
+        } else {
+            const dim3 grid((unsigned)t_tiles, (unsigned)kn);
+            if (eps > 0.f)
+                hipLaunchKernelGGL((pair_kernel<float, float, kField, kPatchKT, kFast>), grid, dim3(kBlock), 0, st, pa);
+            else if (eps == 0.f)
+                hipLaunchKernelGGL((pair_kernel<float, float, kField, kPatchKT, kNanCoinc>), grid, dim3(kBlock), 0, st, pa);
+            else
+                hipLaunchKernelGGL((pair_kernel<float, float, kField, kPatchKT, kRobust>), grid, dim3(kBlock), 0, st, pa);
+        }
         DNP_CHECK_HIP(hipGetLastError());
     }
     return DNP_OK;

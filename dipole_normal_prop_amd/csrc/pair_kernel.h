@@ -1,7 +1,21 @@
-// pair_kernel.h - the all-pairs dipole kernel for CDNA4 (gfx950), shared by the field_grad /
-// potential entry points (dnp_field.hip) and the batched per-patch entry point (dnp_patch.hip).
+// pair_kernel.h - the all-pairs dipole kernels for CDNA4 (gfx950), shared by the field_grad / potential entry
+// points (dnp_field.hip) and the batched per-patch entry point (dnp_patch.hip).  Two kernels, same arithmetic:
 //
-// Work decomposition
+// pair_kernel_scalar - sources through the SCALAR unit (contiguous source rows: every driver's hot case)
+//   A source is the same for all 64 lanes of a wave, so it is fetched with s_load (wave-uniform address, scalar
+//   cache -> SGPRs) and every VALU instruction takes its source operand from an SGPR: no staging, no barrier, no
+//   ds_read, no VGPRs for the source row.  KT = 2 targets per lane in registers (57 VGPRs -> 8 waves per SIMD), a
+//   wave owns 128 consecutive targets.  With FAR, a wave whose targets' bounding box is far from the chunk's box
+//   runs the chunk through the one-transcendental far-field chain (pair_field_far); the drivers sort the cloud by
+//   patch, so ~2/3 of the (wave, patch) combinations of the 100k / 256-patch workload qualify.  Measured on
+//   MI355X (tools/gpu_ab_far.py, interleaved in one process): 4.37 ms per 10^10 pairs against 4.72 ms for the
+//   LDS kernel below.  Why this wins although the instruction count is the same: the per-pair chain is a serial
+//   dependency chain (hipcc schedules one pair after the other) and at the LDS kernel's 3 waves per SIMD the far
+//   chain's 12-deep dependency could not be covered (the same far chain inside the LDS kernel was 8 % SLOWER than
+//   the exact one); at 8 waves per SIMD it is 10 % faster.
+//
+// pair_kernel - sources staged through LDS (row gathers: src_idx != NULL, where a scalar load per gathered row
+//   would be two dependent scalar round trips)
 //   grid.x = target tiles (BLOCK threads x KT targets per lane; KT = 4 for large target sets, 1 for small
 //   ones - swept on gfx950: 4 targets x 2 accumulator sets (134 VGPRs, 3 waves/SIMD) beats 2 x 4 (120 VGPRs,
 //   4 waves) by 2 %, 6 x 2 and 4 x 4 lose to register pressure), grid.y = source chunks.
@@ -9,7 +23,9 @@
 //   the next tile's global loads are in flight while the current tile is consumed) and every
 //   lane accumulates KT targets in registers.  All 64 lanes of a wave read the SAME LDS
 //   address per source (hardware broadcast, conflict-free): one ds_read_b128 + one ds_read_b64
-//   feed KT x 21 VALU instructions.  Output: partial[chunk][target][NC], reduced by a second,
+//   feed KT x 21 VALU instructions.
+//
+// Both: grid = (target tiles) x (source chunks); output partial[chunk][target][NC], reduced by a second,
 //   tiny kernel - deterministic (no float atomics), and the natural place for the reference's
 //   per-leaf Inf/NaN filter (field_utils.py:110-115) - or, when the plan is a single chunk, the final
 //   rows directly (a.out).
@@ -19,7 +35,7 @@
 // which is field_utils.py:96-109 with r^ = r/|r| folded in (see pair_field for the exact chain and
 // for how |r| == 0 contributes exactly 0).  Measured on gfx950 (tools/ubench_*.hip, profiles/r01_ubench_*):
 // v_fma_f32 issues at 2.2 cycles per wave64, v_pk_fma_f32 at 4.1 (no gain from packing), v_rsq/v_rcp/v_sqrt
-// at 8 back to back and ~13 when mixed with FMAs, so the loop costs ~65-70 cycles per 64 pairs per SIMD and
+// at 8 back to back and ~13 when mixed with FMAs, so the exact chain costs ~70 cycles per 64 pairs per SIMD and
 // the FP32 vector ALU is the roofline (DESIGN.md section 4 lists the alternatives that were measured).
 //
 // Accumulation: fp32 inside a run of kFlush = 64 sources, spread over kSets = 2 interleaved accumulator
@@ -70,7 +86,7 @@ struct PairArgs {
     int out_scatter;         // row = tgt_idx[t]
     int accumulate;          // out += result
     int* nonfinite;          // [2] counters of inf / nan leaf components zeroed (direct epilogue), or nullptr
-    F far_d2;                // FAR kernels: squared box distance beyond which the one-transcendental chain is used
+    F far_d2;                // scalar kernel, FAR: squared box distance beyond which the one-transcendental chain runs
     int32_t chunk_off[kMaxChunks + 1];  // by-value CSR offsets when chunk_off_dev == nullptr
 };
 
@@ -194,17 +210,11 @@ __device__ __forceinline__ void pair_potential(F sx, F sy, F sz, F px, F py, F p
 // LDS image of one staged source row: two 16-byte slots, (x,y,z,px) and (py,pz,-,-).
 template <typename F> struct Vec4 { F x, y, z, w; };
 
-// FAR (field mode, kFast only): a wave whose targets' bounding box is farther than sqrt(far_d2) from the bounding
-// box of the current 256-source tile runs the tile through pair_field_far.  The test is wave-uniform (boxes, not
-// pairs), so there is no divergence and no per-pair compare; it pays when sources and targets are spatially
-// coherent runs - the patch-sorted clouds of the drivers.
-template <typename F, typename PT, int MODE, int KT, int V, bool FAR = false>
+template <typename F, typename PT, int MODE, int KT, int V>
 __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
     using M = Math<F>;
     constexpr int NC = (MODE == kField) ? 3 : 1;
-    constexpr bool kFarPath = FAR && MODE == kField && V == kFast;
     __shared__ __attribute__((aligned(16))) Vec4<F> lds[2][kBlock][2];
-    __shared__ F tile_box[2][kBlock / 64][6];      // per staged tile and staging wave: min xyz, max xyz
 
     const int tid = threadIdx.x;
     const int64_t chunk = blockIdx.y;
@@ -234,21 +244,6 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
         }
     }
 
-    // bounding box of this wave's targets (wave-uniform)
-    F tlo[3] = {F(0), F(0), F(0)}, thi[3] = {F(0), F(0), F(0)};
-    if (kFarPath) {
-        F lo[3] = {M::kHuge, M::kHuge, M::kHuge}, hi[3] = {-M::kHuge, -M::kHuge, -M::kHuge};
-#pragma unroll
-        for (int k = 0; k < KT; ++k)
-            if (trow[k] >= 0) {
-                lo[0] = tx[k] < lo[0] ? tx[k] : lo[0]; hi[0] = tx[k] > hi[0] ? tx[k] : hi[0];
-                lo[1] = ty[k] < lo[1] ? ty[k] : lo[1]; hi[1] = ty[k] > hi[1] ? ty[k] : hi[1];
-                lo[2] = tz[k] < lo[2] ? tz[k] : lo[2]; hi[2] = tz[k] > hi[2] ? tz[k] : hi[2];
-            }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { tlo[c] = wave_min<F>(lo[c]); thi[c] = wave_max<F>(hi[c]); }
-    }
-
     double acc[KT][NC];
 #pragma unroll
     for (int k = 0; k < KT; ++k)
@@ -257,10 +252,8 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
 
     // ---- staging helpers -------------------------------------------------------------------
     F g0, g1, g2, g3, g4, g5;
-    bool g_real = false;
     auto load_row = [&](int64_t s) {
-        g_real = s < s_end;
-        if (g_real) {
+        if (s < s_end) {
             const int64_t row = a.src_idx ? a.src_idx[s] : s;
             const F* p = a.src + row * a.ld_src;
             g0 = p[0]; g1 = p[1]; g2 = p[2]; g3 = p[3]; g4 = p[4]; g5 = p[5];
@@ -271,16 +264,6 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
     auto store_row = [&](int buf) {
         lds[buf][tid][0] = Vec4<F>{g0, g1, g2, g3};
         lds[buf][tid][1] = Vec4<F>{g4, g5, F(0), F(0)};
-        if (kFarPath) {    // this wave's 64 staged rows -> their box (padding rows excluded)
-            const F l0 = wave_min<F>(g_real ? g0 : M::kHuge), l1 = wave_min<F>(g_real ? g1 : M::kHuge),
-                    l2 = wave_min<F>(g_real ? g2 : M::kHuge);
-            const F h0 = wave_max<F>(g_real ? g0 : -M::kHuge), h1 = wave_max<F>(g_real ? g1 : -M::kHuge),
-                    h2 = wave_max<F>(g_real ? g2 : -M::kHuge);
-            if ((tid & 63) == 0) {
-                F* b = tile_box[buf][tid >> 6];
-                b[0] = l0; b[1] = l1; b[2] = l2; b[3] = h0; b[4] = h1; b[5] = h2;
-            }
-        }
     };
 
     const int64_t n_src = s_end - s_begin;
@@ -298,26 +281,6 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
         int n_here = (int)((s_end - tile_s) < kBlock ? (s_end - tile_s) : kBlock);
         n_here = (n_here + 3) & ~3;                                // rows past s_end are padding rows (kUnroll | 4)
 
-        bool far_tile = false;
-        if (kFarPath) {
-            F d2box = F(0);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                F slo = tile_box[buf][0][c], shi = tile_box[buf][0][3 + c];
-#pragma unroll
-                for (int w = 1; w < kBlock / 64; ++w) {
-                    const F l = tile_box[buf][w][c], h = tile_box[buf][w][3 + c];
-                    slo = l < slo ? l : slo; shi = h > shi ? h : shi;
-                }
-                F gap = slo - thi[c];
-                const F gap2 = tlo[c] - shi;
-                gap = gap2 > gap ? gap2 : gap;
-                gap = gap > F(0) ? gap : F(0);
-                d2box = M::fma(gap, gap, d2box);
-            }
-            far_tile = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2)) != 0;
-        }
-
         for (int j0 = 0; j0 < n_here; j0 += kFlush) {
             const int j1 = (j0 + kFlush < n_here) ? j0 + kFlush : n_here;   // multiples of kSets
             if (MODE == kField) {
@@ -330,33 +293,17 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
                     for (int k = 0; k < KT; ++k)
 #pragma unroll
                         for (int c = 0; c < 3; ++c) A[u][k][c] = B[u][k][c] = F(0);
-                if (kFarPath && far_tile) {
-                    for (int j = j0; j < j1; j += kUnroll) {
+                for (int j = j0; j < j1; j += kUnroll) {
 #pragma unroll
-                        for (int u = 0; u < kUnroll; ++u) {
-                            const Vec4<F> s0 = lds[buf][j + u][0];
-                            const Vec4<F> s1 = lds[buf][j + u][1];
-                            constexpr int kS = kSets;
+                    for (int u = 0; u < kUnroll; ++u) {
+                        const Vec4<F> s0 = lds[buf][j + u][0];
+                        const Vec4<F> s1 = lds[buf][j + u][1];
+                        constexpr int kS = kSets;
 #pragma unroll
-                            for (int k = 0; k < KT; ++k)
-                                pair_field_far<F>(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx[k], ty[k], tz[k], a.eps,
-                                                  A[u % kS][k][0], A[u % kS][k][1], A[u % kS][k][2], B[u % kS][k][0],
-                                                  B[u % kS][k][1], B[u % kS][k][2]);
-                        }
-                    }
-                } else {
-                    for (int j = j0; j < j1; j += kUnroll) {
-#pragma unroll
-                        for (int u = 0; u < kUnroll; ++u) {
-                            const Vec4<F> s0 = lds[buf][j + u][0];
-                            const Vec4<F> s1 = lds[buf][j + u][1];
-                            constexpr int kS = kSets;
-#pragma unroll
-                            for (int k = 0; k < KT; ++k)
-                                pair_field<F, V>(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx[k], ty[k], tz[k], a.eps,
-                                                 A[u % kS][k][0], A[u % kS][k][1], A[u % kS][k][2], B[u % kS][k][0],
-                                                 B[u % kS][k][1], B[u % kS][k][2]);
-                        }
+                        for (int k = 0; k < KT; ++k)
+                            pair_field<F, V>(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx[k], ty[k], tz[k], a.eps,
+                                             A[u % kS][k][0], A[u % kS][k][1], A[u % kS][k][2], B[u % kS][k][0],
+                                             B[u % kS][k][1], B[u % kS][k][2]);
                     }
                 }
 #pragma unroll
@@ -422,6 +369,190 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
                     PT v = (PT)((MODE == kField) ? -acc[k][c] : acc[k][c]);
                     // patch mode: a slab is the complete dE of one field_grad call (one leaf), so the reference's
                     // Inf/NaN zeroing (field_utils.py:114-115) applies here; otherwise reduce_kernel applies it
+                    if (a.tgt_group && !__builtin_isfinite(v)) v = PT(0);
+                    o[c] = excluded ? PT(0) : v;
+                }
+            }
+        }
+    }
+}
+
+// ---- pair_kernel_scalar: sources through the scalar unit (see the header comment) ------------------------------
+// FAR: a wave whose target box is farther than sqrt(far_d2) from the box of the chunk's sources runs the whole chunk
+// through pair_field_far (one decision per wave and chunk; the chunk's box is found by the workgroup itself).
+template <typename F, int KT, int V, bool FARCHAIN>
+__device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, const int64_t* __restrict__ sidx, int64_t ld,
+                                               int64_t& s, int64_t run_end, const F (&tx)[KT], const F (&ty)[KT],
+                                               const F (&tz)[KT], F eps, double (&acc)[KT][3]) {
+    F A[kSets][KT][3], B[kSets][KT][3];
+#pragma unroll
+    for (int u = 0; u < kSets; ++u)
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) A[u][k][c] = B[u][k][c] = F(0);
+    auto one = [&](int64_t row, int set) {
+        const F* p = src + row * ld;                                    // uniform address: scalar loads
+        const F sx = p[0], sy = p[1], sz = p[2], px = p[3], py = p[4], pz = p[5];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            if (FARCHAIN)
+                pair_field_far<F>(sx, sy, sz, px, py, pz, tx[k], ty[k], tz[k], eps, A[set][k][0], A[set][k][1],
+                                  A[set][k][2], B[set][k][0], B[set][k][1], B[set][k][2]);
+            else
+                pair_field<F, V>(sx, sy, sz, px, py, pz, tx[k], ty[k], tz[k], eps, A[set][k][0], A[set][k][1],
+                                 A[set][k][2], B[set][k][0], B[set][k][1], B[set][k][2]);
+        }
+    };
+    for (; s + kUnroll <= run_end; s += kUnroll) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) one(sidx ? sidx[s + u] : s + u, u % kSets);
+    }
+    for (; s < run_end; ++s) one(sidx ? sidx[s] : s, 0);
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const F as = (kSets == 4) ? (A[0][k][c] + A[1][k][c]) + (A[2 % kSets][k][c] + A[3 % kSets][k][c])
+                                      : (A[0][k][c] + A[1][k][c]);
+            const F bs = (kSets == 4) ? (B[0][k][c] + B[1][k][c]) + (B[2 % kSets][k][c] + B[3 % kSets][k][c])
+                                      : (B[0][k][c] + B[1][k][c]);
+            acc[k][c] += 3.0 * (double)as - (double)bs;
+        }
+}
+
+template <typename F, typename PT, int MODE, int KT, int V, bool FAR = false>
+__global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, PT> a) {
+    using M = Math<F>;
+    constexpr int NC = (MODE == kField) ? 3 : 1;
+    constexpr bool kFarPath = FAR && MODE == kField && V == kFast;
+    __shared__ F chunk_box[kBlock / 64][6];
+    const int tid = threadIdx.x;
+    const int64_t chunk = blockIdx.y;
+    int64_t s_begin, s_end;
+    if (a.chunk_off_dev) {
+        s_begin = a.chunk_off_dev[a.chunk_base + chunk];
+        s_end = a.chunk_off_dev[a.chunk_base + chunk + 1];
+    } else {
+        s_begin = a.chunk_off[chunk];
+        s_end = a.chunk_off[chunk + 1];
+    }
+    const int64_t tile_base = (int64_t)blockIdx.x * (kBlock * KT);
+    F tx[KT], ty[KT], tz[KT];
+    int64_t trow[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const int64_t t = tile_base + (int64_t)(tid >> 6) * (64 * KT) + k * 64 + (tid & 63);   // a wave owns 64 KT consecutive targets
+        trow[k] = -1;
+        tx[k] = ty[k] = tz[k] = F(0);
+        if (t < a.T) {
+            const int64_t row = a.tgt_idx ? a.tgt_idx[t] : t;
+            trow[k] = row;
+            const F* p = a.tgt + row * a.ld_tgt;
+            tx[k] = p[0]; ty[k] = p[1]; tz[k] = p[2];
+        }
+    }
+    const F* __restrict__ src = a.src;
+    const int64_t* __restrict__ sidx = a.src_idx;
+    const int64_t ld = a.ld_src;
+
+    bool far_chunk = false;
+    if (kFarPath) {
+        // box of the chunk's sources (workgroup-cooperative) and of this wave's targets
+        F lo[3] = {M::kHuge, M::kHuge, M::kHuge}, hi[3] = {-M::kHuge, -M::kHuge, -M::kHuge};
+        for (int64_t q = s_begin + tid; q < s_end; q += kBlock) {
+            const F* p = src + (sidx ? sidx[q] : q) * ld;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { lo[c] = p[c] < lo[c] ? p[c] : lo[c]; hi[c] = p[c] > hi[c] ? p[c] : hi[c]; }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lo[c] = wave_min<F>(lo[c]); hi[c] = wave_max<F>(hi[c]); }
+        if ((tid & 63) == 0)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { chunk_box[tid >> 6][c] = lo[c]; chunk_box[tid >> 6][3 + c] = hi[c]; }
+        F tlo[3] = {M::kHuge, M::kHuge, M::kHuge}, thi[3] = {-M::kHuge, -M::kHuge, -M::kHuge};
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+            if (trow[k] >= 0) {
+                tlo[0] = tx[k] < tlo[0] ? tx[k] : tlo[0]; thi[0] = tx[k] > thi[0] ? tx[k] : thi[0];
+                tlo[1] = ty[k] < tlo[1] ? ty[k] : tlo[1]; thi[1] = ty[k] > thi[1] ? ty[k] : thi[1];
+                tlo[2] = tz[k] < tlo[2] ? tz[k] : tlo[2]; thi[2] = tz[k] > thi[2] ? tz[k] : thi[2];
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { tlo[c] = wave_min<F>(tlo[c]); thi[c] = wave_max<F>(thi[c]); }
+        __syncthreads();
+        F d2box = F(0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            F slo = chunk_box[0][c], shi = chunk_box[0][3 + c];
+#pragma unroll
+            for (int w = 1; w < kBlock / 64; ++w) {
+                slo = chunk_box[w][c] < slo ? chunk_box[w][c] : slo;
+                shi = chunk_box[w][3 + c] > shi ? chunk_box[w][3 + c] : shi;
+            }
+            F gap = slo - thi[c];
+            const F gap2 = tlo[c] - shi;
+            gap = gap2 > gap ? gap2 : gap;
+            gap = gap > F(0) ? gap : F(0);
+            d2box = M::fma(gap, gap, d2box);
+        }
+        far_chunk = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2)) != 0;
+    }
+
+    double acc[KT][NC];
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[k][c] = 0.0;
+
+    int64_t s = s_begin;                                    // wave-uniform
+    while (s < s_end) {
+        const int64_t run_end = (s + kFlush < s_end) ? s + kFlush : s_end;
+        if constexpr (MODE == kField) {
+            if (kFarPath && far_chunk) scalar_field_run<F, KT, V, true>(src, sidx, ld, s, run_end, tx, ty, tz, a.eps, acc);
+            else scalar_field_run<F, KT, V, false>(src, sidx, ld, s, run_end, tx, ty, tz, a.eps, acc);
+        } else {
+            F P[kSets][KT];
+#pragma unroll
+            for (int u = 0; u < kSets; ++u)
+#pragma unroll
+                for (int k = 0; k < KT; ++k) P[u][k] = F(0);
+            for (; s < run_end; ++s) {
+                const F* p = src + (sidx ? sidx[s] : s) * ld;
+                const F sx = p[0], sy = p[1], sz = p[2], px = p[3], py = p[4], pz = p[5];
+#pragma unroll
+                for (int k = 0; k < KT; ++k) pair_potential<F>(sx, sy, sz, px, py, pz, tx[k], ty[k], tz[k], P[s & (kSets - 1)][k]);
+            }
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+                acc[k][0] += (kSets == 4) ? (double)((P[0][k] + P[1][k]) + (P[2 % kSets][k] + P[3 % kSets][k]))
+                                          : (double)(P[0][k] + P[1][k]);
+        }
+    }
+
+    const int64_t chunk_id = a.chunk_base + chunk;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const int64_t t = tile_base + (int64_t)(tid >> 6) * (64 * KT) + k * 64 + (tid & 63);   // a wave owns 64 KT consecutive targets
+        if (t < a.T) {
+            bool excluded = false;
+            if (a.tgt_group) excluded = (a.tgt_group[trow[k]] == chunk_id);
+            if (a.out) {
+                F* o = a.out + (a.out_scatter ? trow[k] : t) * a.ld_out;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    F v = (F)((MODE == kField) ? -acc[k][c] : acc[k][c]);
+                    if (!__builtin_isfinite(v)) {
+                        if (a.nonfinite) atomicAdd(a.nonfinite + (v != v ? 1 : 0), 1);
+                        v = F(0);
+                    }
+                    o[c] = a.accumulate ? (F)(o[c] + v) : v;
+                }
+            } else {
+                PT* o = a.partial + ((int64_t)chunk * a.T + t) * NC;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    PT v = (PT)((MODE == kField) ? -acc[k][c] : acc[k][c]);
                     if (a.tgt_group && !__builtin_isfinite(v)) v = PT(0);
                     o[c] = excluded ? PT(0) : v;
                 }

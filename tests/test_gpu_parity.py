@@ -231,7 +231,7 @@ def test_raw_c_abi_gather_scatter_accumulate(dev):
     nbytes = lib.dnp_field_grad_workspace_bytes(700, 1900, 15000)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     rc = lib.dnp_field_grad_f32(_lib.ptr(d_pts), 700, 6, _lib.ptr(d_si), _lib.ptr(d_pts), 1900, 6, _lib.ptr(d_ti),
-                                1e-5, 15000, _lib.ptr(d_E), 3, 1, 1, _lib.ptr(ws), nbytes, _lib.current_stream())
+                                1e-5, 15000, _lib.ptr(d_E), 3, 1, 1, None, _lib.ptr(ws), nbytes, _lib.current_stream())
     assert rc == 0, lib.dnp_last_error()
     torch.cuda.synchronize()
     out = d_E.cpu()
@@ -241,7 +241,7 @@ def test_raw_c_abi_gather_scatter_accumulate(dev):
     assert torch.equal(out[untouched], E0[untouched])
     # too-small workspace is refused, nothing is launched
     rc = lib.dnp_field_grad_f32(_lib.ptr(d_pts), 700, 6, _lib.ptr(d_si), _lib.ptr(d_pts), 1900, 6, _lib.ptr(d_ti),
-                                1e-5, 15000, _lib.ptr(d_E), 3, 1, 1, _lib.ptr(ws), 16, _lib.current_stream())
+                                1e-5, 15000, _lib.ptr(d_E), 3, 1, 1, None, _lib.ptr(ws), 16, _lib.current_stream())
     assert rc == -3
 
 
@@ -731,20 +731,23 @@ def test_point_greedy_never_reads_a_rewritten_normal(dev):
 
 
 def test_nonfinite_leaf_components_are_counted_and_zeroed(dev, capsys):
-    """field_utils.py:110-115: Inf/NaN leaf components are reported ("warning: %d inf in field_grad") and zeroed.
-    A source at 1e30 overflows fp32 in the squared distance -> NaN in that leaf only; with 15000-row leaves the
-    other leaf still contributes."""
+    """field_utils.py:110-115: Inf/NaN leaf components are reported ("warning: %d nan in field_grad") and zeroed.
+    With eps = 0 a target that coincides with a source makes that LEAF's sum 0/0 = NaN for the target's three
+    components (G3 pins the case); with 15000-row leaves the other leaf of a 16000-row source set still
+    contributes.  One warning, three components, the row equal to the reference-class oracle's."""
     gen = torch.Generator().manual_seed(4)
     src = torch.rand(16000, 6, generator=gen) - 0.5
-    src[3, :3] = 1e30                                  # in the first leaf (rows 0..7999)
     tgt = torch.rand(40, 3, generator=gen) - 0.5
-    E = fu.field_grad(src.to(dev), tgt.to(dev))
-    ref = O.field_grad(src, tgt)
+    tgt[5] = src[3, :3]                                # coincides with a source of the first leaf (rows 0..7999)
+    E = fu.field_grad(src.to(dev), tgt.to(dev), eps=0.0)
+    ref = O.field_grad(src, tgt, eps=0.0)
     fu.flush_warnings()
     printed = capsys.readouterr().out
-    assert "nan in field_grad" in printed or "inf in field_grad" in printed
+    assert "warning: 3 nan in field_grad" in printed and "inf in field_grad" not in printed
     assert bool(torch.isfinite(E).all())
-    assert rel_rowwise(E.cpu(), ref) < 1e-4            # the surviving leaf, as in the reference
-    fu.field_grad(src[8000:].to(dev), tgt.to(dev))     # a clean call prints nothing
+    assert rel_rowwise(E.cpu(), ref) < 1e-4            # row 5 = the surviving leaf alone, as in the reference
+    second_leaf = O.field_grad(src[8000:], tgt[5:6], eps=0.0)
+    assert rel_rowwise(E.cpu()[5:6], second_leaf) < 1e-4
+    fu.field_grad(src.to(dev), tgt.to(dev))            # eps > 0: the coincident pair contributes 0, no warning
     fu.flush_warnings()
     assert "field_grad" not in capsys.readouterr().out

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""A/B of the far-field (one-transcendental) path of pair_kernel on the bench workload (100k sphere, 256 patches,
-cloud sorted by patch): the product library against a build with -DDNP_FAR=0, interleaved launches in ONE process
-on ONE device (cdna guide rule 24), plus the accuracy of both against the fp64 oracle on a row sample.
+"""A/B of the pair-kernel variants on the bench workload (100k sphere, 256 patches, cloud sorted by patch):
+    far     the product library: scalar-unit kernel + far-field (one-transcendental) chain
+    exact   the same kernel built with -DDNP_FAR=0 (exact chain everywhere)
+    lds     the LDS-staged kernel of round 1 (-DDNP_FORCE_LDS=1)
+plus any variant listed in AB_VARIANTS="name=flags;...", interleaved launches in ONE process on ONE device (cdna
+guide rule 24), and the accuracy of each against the fp64 oracle on a row sample.
 
-    python tools/gpu_ab_far.py            (on the GPU box; builds tools/bin/libdnp_nofar.so first if missing)
+    python tools/gpu_ab_far.py            (on the GPU box; builds the variants under tools/bin/ first if missing)
 """
 import ctypes
 import os
@@ -29,10 +32,15 @@ def bind(path):
 
 
 def main():
-    if not os.path.exists(NOFAR):
-        build.build(extra_flags=["-DDNP_FAR=0"], out=NOFAR, verbose=False)
     build.build(verbose=False)
-    libs = {"far": bind(build.LIB), "exact": bind(NOFAR)}
+    libs = {"far": bind(build.LIB)}
+    extra = "exact=-DDNP_FAR=0;lds=-DDNP_FORCE_LDS=1;" + os.environ.get("AB_VARIANTS", "")
+    for item in [v for v in extra.split(";") if v]:
+        name, flags = item.split("=", 1)
+        path = os.path.join(ROOT, "tools", "bin", f"libdnp_{name}.so")
+        if not os.path.exists(path):
+            build.build(extra_flags=flags.split(), out=path, verbose=False)
+        libs[name] = bind(path)
     dev = torch.device("cuda:0")
     pc = sphere_cloud()
     patches = fibonacci_patches(pc)
@@ -54,7 +62,7 @@ def main():
     torch.cuda.synchronize()
     times = {k: [] for k in libs}
     for rnd in range(24):
-        for name in (("far", "exact") if rnd % 2 == 0 else ("exact", "far")):
+        for name in (list(libs) if rnd % 2 == 0 else list(libs)[::-1]):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             launch(name)
