@@ -22,9 +22,9 @@ SIGNATURES = {
     "dnp_field_grad_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "dnp_potential_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "dnp_field_grad_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, ctypes.c_float,
-                                          _c_i64, _c_p, _c_i64, ctypes.c_int, ctypes.c_int, _c_p, _c_p, _c_sz, _c_p]),
+                                          _c_i64, _c_p, _c_i64, ctypes.c_int, ctypes.c_int, _c_p, _c_p, _c_p, _c_sz, _c_p]),
     "dnp_field_grad_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, ctypes.c_double,
-                                          _c_i64, _c_p, _c_i64, ctypes.c_int, ctypes.c_int, _c_p, _c_p, _c_sz, _c_p]),
+                                          _c_i64, _c_p, _c_i64, ctypes.c_int, ctypes.c_int, _c_p, _c_p, _c_p, _c_sz, _c_p]),
     "dnp_potential_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p,
                                          _c_i64, _c_p, _c_sz, _c_p]),
     "dnp_potential_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p,

@@ -27,10 +27,6 @@ static inline int64_t min_chunk(int64_t S) { const int64_t m = S / 64; return m 
 constexpr int kKTScalar = 2, kKTLds = 4;
 constexpr int64_t kTilesForLarge = 64;     // ... used once that still leaves >= 64 target tiles
 constexpr size_t kSlabCap = (size_t)1 << 30;  // bytes of partial slab per round
-// workgroups of 256 threads a CU holds at once: the LDS kernel at KT = 4 needs 134 VGPRs (3 waves per SIMD);
-// KT = 1 and the scalar kernel (57 VGPRs at KT = 2) fit 8
-constexpr int kResidentLds4 = 3, kResidentFull = 8;
-
 struct Plan {
     // one entry per round; every round is a run of whole leaves
     struct Round {
@@ -53,43 +49,21 @@ static void split_leaves(int64_t lo, int64_t hi, int64_t max_pts, std::vector<in
     }
 }
 
-static int compute_units() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            cus = n;
-        else {
-            (void)hipGetLastError();
-            cus = 256;                       // MI355X; planning must also work where no device is visible
-        }
-    }
-    return cus;
-}
+#ifndef DNP_K1_FAR        // far-field chain in the generic entry points (pays only for spatially sorted clouds)
+#define DNP_K1_FAR 1
+#endif
 
-// Number of source chunks for one launch.  All workgroups of a launch do the same amount of work, so the launch
-// runs in ceil(blocks / resident) rounds of equal length: pick the chunk count that wastes the least of the last
-// round while keeping the fp64 partial slab (24 B per target and chunk, written once and read once) small.
+// Number of source chunks for one launch: enough that the launch has ~kWantBlocks workgroups (about four
+// resident sets of the scalar kernel).  Measured on MI355X (tools/gpu_k1_ab.py, profiles/r02_k1_planning.txt): more,
+// shorter chunks beat a plan that fills the chip exactly once (30k x 30k: 517 us with 64-200 chunks against 598 us
+// with 17), and the chunk count hardly matters beyond that; the fp64 partial slab (24 B per target and chunk) is
+// written once and read once and stays below 3 % of the time.
+constexpr int64_t kWantBlocks = 8192;
 static int64_t choose_chunks(int64_t S, int64_t T, int64_t t_tiles, int kt, int64_t n_leaves, int64_t cap) {
-    const int64_t slots = (int64_t)compute_units() * (kt == kKTLds ? kResidentLds4 : kResidentFull);
-    const int64_t longest = S / min_chunk(S) > 0 ? S / min_chunk(S) : 1;   // most chunks the minimum length allows
-    int64_t hi = cap < longest ? cap : longest;
-    if (hi < n_leaves) hi = n_leaves;
-    int64_t lo = n_leaves;
-    double best_cost = 0;
-    int64_t best = lo;
-    for (int64_t n = lo; n <= hi; ++n) {
-        const int64_t blocks = t_tiles * n;
-        const double rounds = (double)ceil_div(blocks, slots);
-        // one round = one workgroup's S/n sources x (256 kt) targets at the chip rate / slots; the slab costs
-        // 48 bytes per target and chunk at ~4 TB/s; a round also pays ~1 us of launch/drain
-        const double t_pairs = rounds * ((double)S / n) * (256.0 * kt) / (2.1e12 / (double)slots);
-        const double t_slab = (n > 1 ? 48.0 * (double)T * n / 4e12 : 0.0);
-        const double cost = t_pairs + t_slab + rounds * 1e-6;
-        if (n == lo || cost < best_cost) { best_cost = cost; best = n; }
-    }
-    return best;
+    (void)S; (void)T; (void)kt; (void)cap;
+    int64_t want = ceil_div(kWantBlocks, t_tiles);
+    if (want < n_leaves) want = n_leaves;
+    return want;
 }
 
 static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem, bool scalar_kernel) {
@@ -100,6 +74,9 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
     // small problems are latency bound: prefer many short workgroups (1 target per lane, chunks down to 64
     // sources); large ones amortise the source fetch over 2 (scalar kernel) / 4 (LDS kernel) targets per lane
     plan.kt = (T >= (int64_t)kBlock * kKTLarge * kTilesForLarge) ? kKTLarge : 1;
+#ifdef DNP_FORCE_KT       // planning experiments only
+    plan.kt = DNP_FORCE_KT;
+#endif
     const int64_t t_tiles = ceil_div(T > 0 ? T : 1, (int64_t)kBlock * plan.kt);
     const int64_t n_leaves = (int64_t)cuts.size();
     // chunk cap per round from the slab budget (at least one)
@@ -107,6 +84,10 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
     if (cap > kMaxChunks) cap = kMaxChunks;
     if (cap < 1) cap = 1;
     int64_t want = choose_chunks(S, T, t_tiles, plan.kt, n_leaves, cap >= n_leaves ? cap : kMaxChunks);
+#ifdef DNP_FORCE_CHUNKS   // planning experiments only
+    want = DNP_FORCE_CHUNKS;
+#endif
+
     if (want < n_leaves) want = n_leaves;
     // keep all leaves in ONE round whenever they fit: a round is two launches
     if (n_leaves <= cap && want > cap) want = cap;
@@ -213,7 +194,7 @@ template <typename F, int MODE>
 static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
                      const F* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
                      F eps, int64_t max_pts, F* out, int64_t ld_out, int out_scatter, int accumulate,
-                     int* nonfinite, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                     int* nonfinite, int* nonfinite_host, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     constexpr int NC = (MODE == kField) ? 3 : 1;
     clear_error();
     DNP_REQUIRE(S >= 0 && T >= 0, "negative size S=%lld T=%lld", (long long)S, (long long)T);
@@ -269,7 +250,7 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
 #define DNP_LAUNCH_PAIR(KT, V) \
     hipLaunchKernelGGL((pair_kernel<F, double, MODE, KT, V>), grid, dim3(kBlock), 0, stream, pa)
 #define DNP_LAUNCH_SCALAR(KT, V) \
-    hipLaunchKernelGGL((pair_kernel_scalar<F, double, MODE, KT, V, (sizeof(F) == 4)>), grid, dim3(kBlock), 0, stream, pa)
+    hipLaunchKernelGGL((pair_kernel_scalar<F, double, MODE, KT, V, (sizeof(F) == 4 && DNP_K1_FAR)>), grid, dim3(kBlock), 0, stream, pa)
         if (scalar_kernel) {
             if (plan.kt == kKTScalar) {
                 if (variant == kFast) DNP_LAUNCH_SCALAR(kKTScalar, kFast);
@@ -304,6 +285,9 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
         DNP_CHECK_HIP(hipGetLastError());
         first = false;
     }
+    // the counters (and the caller's "landed" stamp behind them) travel to pinned host memory behind the kernels
+    if (nonfinite && nonfinite_host)
+        DNP_CHECK_HIP(hipMemcpyAsync(nonfinite_host, nonfinite, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
     return DNP_OK;
 }
 
@@ -331,17 +315,21 @@ size_t dnp_potential_workspace_bytes(int64_t S, int64_t T, int64_t max_pts) {
 int dnp_field_grad_f32(const float* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
                        const float* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
                        float eps, int64_t max_pts, float* out, int64_t ld_out, int out_scatter,
-                       int accumulate, int32_t* nonfinite, void* workspace, size_t workspace_bytes, void* stream) {
+                       int accumulate, int32_t* nonfinite, int32_t* nonfinite_host, void* workspace,
+                       size_t workspace_bytes, void* stream) {
     return run_pairs<float, kField>(src, S, ld_src, src_idx, tgt, T, ld_tgt, tgt_idx, eps, max_pts, out, ld_out,
-                                    out_scatter, accumulate, nonfinite, workspace, workspace_bytes, (hipStream_t)stream);
+                                    out_scatter, accumulate, nonfinite, nonfinite_host, workspace, workspace_bytes,
+                                    (hipStream_t)stream);
 }
 
 int dnp_field_grad_f64(const double* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
                        const double* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
                        double eps, int64_t max_pts, double* out, int64_t ld_out, int out_scatter,
-                       int accumulate, int32_t* nonfinite, void* workspace, size_t workspace_bytes, void* stream) {
+                       int accumulate, int32_t* nonfinite, int32_t* nonfinite_host, void* workspace,
+                       size_t workspace_bytes, void* stream) {
     return run_pairs<double, kField>(src, S, ld_src, src_idx, tgt, T, ld_tgt, tgt_idx, eps, max_pts, out, ld_out,
-                                     out_scatter, accumulate, nonfinite, workspace, workspace_bytes, (hipStream_t)stream);
+                                     out_scatter, accumulate, nonfinite, nonfinite_host, workspace, workspace_bytes,
+                                     (hipStream_t)stream);
 }
 
 int dnp_potential_f32(const float* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
@@ -349,7 +337,7 @@ int dnp_potential_f32(const float* src, int64_t S, int64_t ld_src, const int64_t
                       int64_t max_pts, float* out, int64_t ld_out,
                       void* workspace, size_t workspace_bytes, void* stream) {
     return run_pairs<float, kPotential>(src, S, ld_src, src_idx, tgt, T, ld_tgt, tgt_idx, 0.f, max_pts, out, ld_out,
-                                        0, 0, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+                                        0, 0, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int dnp_potential_f64(const double* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
@@ -357,7 +345,7 @@ int dnp_potential_f64(const double* src, int64_t S, int64_t ld_src, const int64_
                       int64_t max_pts, double* out, int64_t ld_out,
                       void* workspace, size_t workspace_bytes, void* stream) {
     return run_pairs<double, kPotential>(src, S, ld_src, src_idx, tgt, T, ld_tgt, tgt_idx, 0.0, max_pts, out, ld_out,
-                                         0, 0, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+                                         0, 0, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -377,7 +377,13 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
     }
 }
 
-// ---- pair_kernel_scalar: sources through the scalar unit (see the header comment) ------------------------------
+// ---- pair_kernel_scalar: sources through the scalar unit (see the header comment); contiguous source rows only
+// (a.src_idx is ignored: the launchers send gathered sources to pair_kernel) -------------------------------------
+// NOTE ON THIS KERNEL'S SOURCE FORM.  hipcc's placement of the s_load / s_waitcnt pairs in the two inner loops is
+// very sensitive to how the loop is written: semantically identical variants of scalar_field_run (row gather ternary
+// removed; loads hoisted in front of the group; explicit next-group prefetch) measured 4.56-5.14 ms per 10^10 pairs
+// against 4.36-4.42 ms for the form below in interleaved same-process A/B runs (profiles/r02_ab_scalar_forms.txt).
+// Re-run tools/gpu_ab_far.py after ANY edit here.
 // FAR: a wave whose target box is farther than sqrt(far_d2) from the box of the chunk's sources runs the whole chunk
 // through pair_field_far (one decision per wave and chunk; the chunk's box is found by the workgroup itself).
 template <typename F, int KT, int V, bool FARCHAIN>

@@ -14,6 +14,8 @@ Reference lines each function mirrors are cited in its docstring.
 """
 from typing import List, Optional, Tuple
 
+import atexit
+import ctypes
 import threading
 
 import numpy as np
@@ -106,8 +108,9 @@ def _idx(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
 
 
 def _pairs_into(kind: str, src, src_idx, tgt, tgt_idx, eps, max_pts, out, out_scatter=False, accumulate=False,
-                nonfinite=None):
-    """Launch K1/K2 on staged device tensors.  src/tgt/out live on the compute device."""
+                nonfinite=(None, None)):
+    """Launch K1/K2 on staged device tensors.  src/tgt/out live on the compute device.  nonfinite = (device
+    pointer, pinned host pointer) of the three-int warning slot of this call, as ctypes pointers or None."""
     lib = _lib.require_device()
     S = src.shape[0] if src_idx is None else src_idx.shape[0]
     T = tgt.shape[0] if tgt_idx is None else tgt_idx.shape[0]
@@ -123,8 +126,8 @@ def _pairs_into(kind: str, src, src_idx, tgt, tgt_idx, eps, max_pts, out, out_sc
             fn = lib.dnp_field_grad_f64 if f64 else lib.dnp_field_grad_f32
             rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(src_idx), _lib.ptr(tgt), T, _ld(tgt), _lib.ptr(tgt_idx),
                     float(eps), int(max_pts), _lib.ptr(out), out.stride(0) if out.shape[0] > 1 else 3,
-                    int(bool(out_scatter)), int(bool(accumulate)), _lib.ptr(nonfinite), _lib.ptr(ws), ws.numel(),
-                    stream)
+                    int(bool(out_scatter)), int(bool(accumulate)), nonfinite[0], nonfinite[1], _lib.ptr(ws),
+                    ws.numel(), stream)
         else:
             fn = lib.dnp_potential_f64 if f64 else lib.dnp_potential_f32
             rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(src_idx), _lib.ptr(tgt), T, _ld(tgt), _lib.ptr(tgt_idx),
@@ -134,50 +137,49 @@ def _pairs_into(kind: str, src, src_idx, tgt, tgt_idx, eps, max_pts, out, out_sc
 
 
 # ---- the reference's "warning: %d inf in field_grad" prints (field_utils.py:110-113) -----------------------------
-# The kernels count the Inf / NaN leaf components they zero; the two counters of a call travel to pinned host
-# memory with an asynchronous copy, and the line is printed as soon as the copy has landed - at the latest by the
-# next call on this thread, by flush_warnings() or at interpreter exit - so that a field_grad call never waits
-# for the device just to find out that there is nothing to warn about.
+# The kernels count the Inf / NaN leaf components they zero into a three-int slot {inf, nan, stamp = 1} of a small
+# device ring; the library copies the slot to pinned host memory asynchronously behind the kernels, and the host
+# copy's stamp says when it has landed.  Per call this costs pointer arithmetic only.  The line is printed as soon
+# as a later call on this thread finds the copy landed - at the latest by flush_warnings() or interpreter exit -
+# so that a field_grad call never waits for the device just to find out that there is nothing to warn about.
 _WARN_RING = 64
 
 
 class _WarnState:
     def __init__(self, dev):
         self.dev = dev
-        self.ring = torch.zeros((_WARN_RING, 2), dtype=torch.int32, device=dev)
-        self.host = torch.zeros((_WARN_RING, 2), dtype=torch.int32).pin_memory()
-        self.slot = 0
-        self.pending = []          # (event, slot)
+        self.ring = torch.zeros((_WARN_RING, 3), dtype=torch.int32, device=dev)
+        self.ring[:, 2] = 1                                           # the "landed" stamp
+        self.host = torch.zeros((_WARN_RING, 3), dtype=torch.int32).pin_memory()
+        self.view = self.host.numpy()
+        self.dev_base, self.host_base = self.ring.data_ptr(), self.host.data_ptr()
+        self.head = 0             # next slot to hand out
+        self.tail = 0             # oldest slot not yet reported
+        torch.cuda.current_stream(dev).synchronize()                  # the ring is initialised before its first use
 
     def next_slot(self):
-        if self.slot == _WARN_RING:             # every slot has been used once: drain, then start over
+        if self.head - self.tail >= _WARN_RING:                       # every slot is in flight: wait for the oldest
             self.drain(block=True)
-            self.ring.zero_()
-            self.slot = 0
-        i = self.slot
-        self.slot += 1
-        return i
-
-    def submit(self, i):
-        self.host[i].copy_(self.ring[i], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.dev))
-        self.pending.append((ev, i))
+        i = self.head % _WARN_RING
+        self.head += 1
+        return (ctypes.c_void_p(self.dev_base + 12 * i), ctypes.c_void_p(self.host_base + 12 * i))
 
     def drain(self, block=False):
-        keep = []
-        for ev, i in self.pending:
-            if block:
-                ev.synchronize()
-            elif not ev.query():
-                keep.append((ev, i))
-                continue
-            n_inf, n_nan = int(self.host[i, 0]), int(self.host[i, 1])
+        if block and self.tail < self.head:
+            torch.cuda.synchronize(self.dev)
+        while self.tail < self.head:
+            i = self.tail % _WARN_RING
+            if self.view[i, 2] != 1:
+                break                                                 # not landed yet (copies land in order)
+            n_inf, n_nan = int(self.view[i, 0]), int(self.view[i, 1])
             if n_inf:
                 print("warning: %d inf in field_grad" % n_inf)
             if n_nan:
                 print("warning: %d nan in field_grad" % n_nan)
-        self.pending = keep
+            if n_inf or n_nan:
+                self.ring[i, :2] = 0                                  # rare: re-arm the slot's counters
+            self.view[i, :] = 0
+            self.tail += 1
 
 
 _warn_states = []
@@ -204,8 +206,6 @@ def flush_warnings() -> None:
         st.drain(block=True)
 
 
-import atexit  # noqa: E402
-
 atexit.register(lambda: flush_warnings() if _warn_states else None)
 
 
@@ -227,9 +227,7 @@ def _field_like(kind, sources, means, eps, recursive, max_pts):
             # the reference prints (never raises) when a leaf produced Inf/NaN, then zeroes them
             st = _warn_state(dev)
             st.drain()
-            slot = st.next_slot()
-            _pairs_into(kind, src, None, tgt, None, eps, max_pts if recursive else 0, out, nonfinite=st.ring[slot])
-            st.submit(slot)
+            _pairs_into(kind, src, None, tgt, None, eps, max_pts if recursive else 0, out, nonfinite=st.next_slot())
         else:
             _pairs_into(kind, src, None, tgt, None, eps, max_pts if recursive else 0, out)
     return out.to(device=in_dev, dtype=in_dtype) if (out.device != in_dev or out.dtype != in_dtype) else out

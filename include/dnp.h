@@ -60,8 +60,11 @@ const char* dnp_last_error(void);      /* thread-local, never NULL */
  *
  * out row for target j is  out + (out_scatter ? tgt_idx[j] : j) * ld_out  (3 floats);
  * accumulate != 0 adds to what is there (E[mask] = E[mask] + dE, field_utils.py:331).
- * nonfinite (device int32[2], may be NULL): [0] += number of Inf, [1] += number of NaN leaf components that
- * were zeroed - what the reference prints as "warning: %d inf/nan in field_grad" (field_utils.py:110-113).
+ * nonfinite (device int32[3], may be NULL): [0] += number of Inf, [1] += number of NaN leaf components that
+ * were zeroed - what the reference prints as "warning: %d inf/nan in field_grad" (field_utils.py:110-113); [2] is
+ * the caller's and is not touched.  nonfinite_host (PINNED host int32[3], may be NULL): the three ints are copied
+ * there with an asynchronous copy behind the kernels, so a caller that keeps a non-zero stamp in [2] can tell from
+ * the host copy alone when the counters of this call have landed - no event, no synchronisation.
  */
 size_t dnp_field_grad_workspace_bytes(int64_t S, int64_t T, int64_t max_pts);
 
@@ -69,14 +72,14 @@ int dnp_field_grad_f32(const float* src, int64_t S, int64_t ld_src, const int64_
                        const float* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
                        float eps, int64_t max_pts,
                        float* out, int64_t ld_out, int out_scatter, int accumulate, int32_t* nonfinite,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       int32_t* nonfinite_host, void* workspace, size_t workspace_bytes, void* stream);
 
 /* fp64 variant: the socket path of the reference feeds float64 clouds (util.py:71-77). */
 int dnp_field_grad_f64(const double* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
                        const double* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
                        double eps, int64_t max_pts,
                        double* out, int64_t ld_out, int out_scatter, int accumulate, int32_t* nonfinite,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       int32_t* nonfinite_host, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K2: dipole potential  (replaces field_utils.potential, field_utils.py:12-55) ------
  *

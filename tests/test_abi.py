@@ -47,12 +47,12 @@ def test_version_and_error_string(lib):
 
 def test_argument_validation_needs_no_device(lib):
     # negative sizes / bad leading dimensions are rejected before any HIP call
-    rc = lib.dnp_field_grad_f32(None, -1, 6, None, None, 4, 3, None, 1e-5, 0, None, 3, 0, 0, None, None, 0, None)
+    rc = lib.dnp_field_grad_f32(None, -1, 6, None, None, 4, 3, None, 1e-5, 0, None, 3, 0, 0, None, None, None, 0, None)
     assert rc == -1 and b"negative" in lib.dnp_last_error()
     dummy = ctypes.c_void_p(16)
-    rc = lib.dnp_field_grad_f32(dummy, 4, 5, None, dummy, 4, 3, None, 1e-5, 0, dummy, 3, 0, 0, None, None, 0, None)
+    rc = lib.dnp_field_grad_f32(dummy, 4, 5, None, dummy, 4, 3, None, 1e-5, 0, dummy, 3, 0, 0, None, None, None, 0, None)
     assert rc == -1 and b"ld_src" in lib.dnp_last_error()
-    rc = lib.dnp_field_grad_f32(dummy, 4, 6, None, dummy, 4, 3, None, 1e-5, 0, dummy, 3, 0, 0, None, None, 0, None)
+    rc = lib.dnp_field_grad_f32(dummy, 4, 6, None, dummy, 4, 3, None, 1e-5, 0, dummy, 3, 0, 0, None, None, None, 0, None)
     assert rc == -3 and b"workspace" in lib.dnp_last_error()
     rc = lib.dnp_point_greedy_f32(dummy, 2 ** 20, 6, 0, 1e-6, 0, None, None, 0, 0, None, 0, None)
     assert rc == -1 and b"exceeds" in lib.dnp_last_error()

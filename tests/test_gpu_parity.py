@@ -231,7 +231,7 @@ def test_raw_c_abi_gather_scatter_accumulate(dev):
     nbytes = lib.dnp_field_grad_workspace_bytes(700, 1900, 15000)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     rc = lib.dnp_field_grad_f32(_lib.ptr(d_pts), 700, 6, _lib.ptr(d_si), _lib.ptr(d_pts), 1900, 6, _lib.ptr(d_ti),
-                                1e-5, 15000, _lib.ptr(d_E), 3, 1, 1, None, _lib.ptr(ws), nbytes, _lib.current_stream())
+                                1e-5, 15000, _lib.ptr(d_E), 3, 1, 1, None, None, _lib.ptr(ws), nbytes, _lib.current_stream())
     assert rc == 0, lib.dnp_last_error()
     torch.cuda.synchronize()
     out = d_E.cpu()
@@ -241,7 +241,7 @@ def test_raw_c_abi_gather_scatter_accumulate(dev):
     assert torch.equal(out[untouched], E0[untouched])
     # too-small workspace is refused, nothing is launched
     rc = lib.dnp_field_grad_f32(_lib.ptr(d_pts), 700, 6, _lib.ptr(d_si), _lib.ptr(d_pts), 1900, 6, _lib.ptr(d_ti),
-                                1e-5, 15000, _lib.ptr(d_E), 3, 1, 1, None, _lib.ptr(ws), 16, _lib.current_stream())
+                                1e-5, 15000, _lib.ptr(d_E), 3, 1, 1, None, None, _lib.ptr(ws), 16, _lib.current_stream())
     assert rc == -3
 
 
@@ -593,7 +593,7 @@ def test_fuzz_shapes_strides_gathers_against_oracle(dev):
         nbytes = lib.dnp_field_grad_workspace_bytes(S, T, max_pts)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         rc = lib.dnp_field_grad_f32(_lib.ptr(d_src), S, ld_s, _lib.ptr(d_si), _lib.ptr(d_tgt), T, ld_t, _lib.ptr(d_ti),
-                                    eps, max_pts, _lib.ptr(d_out), 3, int(scatter), int(accumulate), None, _lib.ptr(ws),
+                                    eps, max_pts, _lib.ptr(d_out), 3, int(scatter), int(accumulate), None, None, _lib.ptr(ws),
                                     nbytes, _lib.current_stream())
         assert rc == 0, (case, lib.dnp_last_error())
         torch.cuda.synchronize()

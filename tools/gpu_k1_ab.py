@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""A/B of planning / kernel variants of the generic field_grad entry point (dnp_field_grad_f32: pair kernel + reduce)
+on fandisk all-pairs (BASELINE config 2) and the 100k sphere, HIP events, interleaved in one process.
+    K1_VARIANTS="name=flags;name=flags" python tools/gpu_k1_ab.py"""
+import ctypes, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_golden  # noqa: E402
+from dipole_normal_prop_amd import _lib, build  # noqa: E402
+from tools.gpu_check import sphere  # noqa: E402
+
+
+def bind(path):
+    lib = ctypes.CDLL(path)
+    for name in ("dnp_field_grad_f32", "dnp_field_grad_workspace_bytes"):
+        res, args = _lib.SIGNATURES[name]
+        getattr(lib, name).restype, getattr(lib, name).argtypes = res, args
+    return lib
+
+
+def main():
+    build.build(verbose=False)
+    libs = {"product": bind(build.LIB)}
+    for item in [v for v in os.environ.get("K1_VARIANTS", "").split(";") if v]:
+        name, flags = item.split("=", 1)
+        path = os.path.join(ROOT, "tools", "bin", f"libdnp_{name}.so")
+        if not os.path.exists(path):
+            build.build(extra_flags=flags.split(), out=path, verbose=False)
+        libs[name] = bind(path)
+    dev = torch.device("cuda:0")
+    clouds = {"fandisk": torch.from_numpy(load_golden("G5_fandisk_allpairs")["pc"]).to(dev), "sphere3k": sphere(3000).to(dev),
+              "sphere30k": sphere(30000).to(dev), "sphere100k": sphere(100000).to(dev)}
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for cname, pc in clouds.items():
+        n = pc.shape[0]
+        out = torch.empty(n, 3, device=dev)
+        ws = {k: torch.empty(lib.dnp_field_grad_workspace_bytes(n, n, 15000), dtype=torch.uint8, device=dev) for k, lib in libs.items()}
+
+        def launch(name):
+            rc = libs[name].dnp_field_grad_f32(_lib.ptr(pc), n, 6, None, _lib.ptr(pc), n, 6, None, 1e-5, 15000, _lib.ptr(out), 3, 0, 0,
+                                               None, None, _lib.ptr(ws[name]), ws[name].numel(), stream)
+            assert rc == 0
+        for name in libs:
+            for _ in range(3):
+                launch(name)
+        torch.cuda.synchronize()
+        times = {k: [] for k in libs}
+        reps = 30 if n < 50000 else 8
+        for rnd in range(reps):
+            for name in (list(libs) if rnd % 2 == 0 else list(libs)[::-1]):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); launch(name); b.record()
+                torch.cuda.synchronize()
+                times[name].append(a.elapsed_time(b))
+        for name, ts in times.items():
+            ts = np.array(ts) * 1e3
+            print(f"{cname:11s} {name:12s} median {np.median(ts):9.1f} us  min {ts.min():9.1f}  ({n * n / np.median(ts) / 1e3:7.1f} Gpairs/s)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

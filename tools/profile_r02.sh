@@ -1,0 +1,15 @@
+#!/bin/bash
+# rocprofv3 evidence for bench.py (run on the GPU box through gpurun): kernel-trace stats, then the
+# PMC passes in runs of their own (never combined with a trace domain other than --kernel-trace).
+set -e
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof
+mkdir -p $OUT
+ARGS="--steps 10 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o r02 -- python3 $R/bench.py $ARGS > $OUT/trace_stdout.txt 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o r02 -- python3 $R/bench.py $ARGS > $OUT/pmc_fetch_stdout.txt 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o r02 -- python3 $R/bench.py $ARGS > $OUT/pmc_write_stdout.txt 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -o r02 -- python3 $R/bench.py $ARGS > $OUT/pmc_sq_stdout.txt 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc_misc -o r02 -- python3 $R/bench.py $ARGS > $OUT/pmc_misc_stdout.txt 2>&1 || true
+find $OUT -name "*.csv" | head -50

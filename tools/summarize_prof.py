@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 CSVs under gpurun_out/prof (tools/profile_r01.sh) into the committed summaries
+"""Turn the rocprofv3 CSVs under gpurun_out/prof (tools/profile_r02.sh) into the committed summaries
 under profiles/:  <round>_kernel_stats.csv (the --stats table), <round>_pmc_summary.md and
 <round>_pmc_traffic.json (HBM bytes per launch of the dominant kernel, read back by bench.py).
 
@@ -15,7 +15,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -23,7 +23,7 @@ os.makedirs(dst, exist_ok=True)
 
 def counters(sub):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
-    path = os.path.join(src, sub, "r01_counter_collection.csv")
+    path = os.path.join(src, sub, f"{rnd}_counter_collection.csv")
     if not os.path.exists(path):
         return d
     for r in csv.DictReader(open(path)):
@@ -31,8 +31,8 @@ def counters(sub):
     return d
 
 
-shutil.copy(os.path.join(src, "trace", "r01_kernel_stats.csv"), os.path.join(dst, f"{rnd}_kernel_stats.csv"))
-stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "trace", "r01_kernel_stats.csv")))}
+shutil.copy(os.path.join(src, "trace", f"{rnd}_kernel_stats.csv"), os.path.join(dst, f"{rnd}_kernel_stats.csv"))
+stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "trace", f"{rnd}_kernel_stats.csv")))}
 allc = collections.defaultdict(dict)
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
     for k, v in counters(sub).items():
@@ -41,7 +41,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
 
 lines = [f"# {rnd}: rocprofv3 summary of `python bench.py --steps 10 --warmup 2 --no-cpu-baseline` (1x MI355X)", "",
          "Per-dispatch averages. Kernel-trace stats and every PMC group come from separate runs "
-         "(tools/profile_r01.sh).", ""]
+         "(tools/profile_r02.sh).", ""]
 traffic = {}
 for k in sorted(allc, key=lambda n: -float(stats.get(n, {"TotalDurationNs": 0})["TotalDurationNs"])):
     if "dnp::" not in k:
@@ -56,7 +56,7 @@ for k in sorted(allc, key=lambda n: -float(stats.get(n, {"TotalDurationNs": 0})[
         f, w = c.get("FETCH_SIZE", 0.0) * 1024, c.get("WRITE_SIZE", 0.0) * 1024
         lines.append(f"- HBM: FETCH_SIZE {f / 1e6:.1f} MB raw ({2 * f / 1e6:.1f} MB with the gfx950 2x wide-read correction as "
                      f"an upper bound), WRITE_SIZE {w / 1e6:.1f} MB -> {(f + w) / 1e6:.1f} .. {(2 * f + w) / 1e6:.1f} MB per launch")
-        if "pair_kernel" in k:
+        if "pair_kernel" in k and "float, float" in k:
             traffic = {"kernel": k, "fetch_bytes_raw": f, "write_bytes": w, "hbm_bytes_per_launch": f + w,
                        "hbm_bytes_per_launch_upper": 2 * f + w,
                        "avg_launch_us": float(st["AverageNs"]) / 1e3 if st else None}
