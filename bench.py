@@ -287,7 +287,7 @@ def main():
         if fake > 1 and world == 1:
             out["fake_world"] = fake          # NOT a measurement of `fake` GPUs: one rank's share on one GPU
         if world == 1 and not (fake > 1):
-            ranges = util.PatchList(torch.arange(N_POINTS, device=dev), sizes)
+            ranges = util.PatchList(torch.arange(N_POINTS, device=dev), sizes, disjoint=True)
             out["other_configs"] = other_configs(dev, fu, util, pts, ranges)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pc_cpu)

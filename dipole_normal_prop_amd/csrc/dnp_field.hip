@@ -199,7 +199,11 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
     clear_error();
     DNP_REQUIRE(S >= 0 && T >= 0, "negative size S=%lld T=%lld", (long long)S, (long long)T);
     DNP_REQUIRE(S <= INT32_MAX, "S=%lld exceeds the 2^31-1 source rows one call supports", (long long)S);
-    if (T == 0) return DNP_OK;
+    if (T == 0) {
+        if (nonfinite && nonfinite_host)
+            DNP_CHECK_HIP(hipMemcpyAsync(nonfinite_host, nonfinite, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        return DNP_OK;
+    }
     DNP_REQUIRE(tgt && out, "NULL tgt/out pointer");
     DNP_REQUIRE(S == 0 || src, "NULL src pointer");
     DNP_REQUIRE(ld_src >= 6 || S == 0, "ld_src=%lld < 6", (long long)ld_src);
@@ -208,6 +212,8 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
     DNP_REQUIRE(!out_scatter || tgt_idx, "out_scatter requires tgt_idx");
 
     if (S == 0) {  // empty sum: zeros (the reference's sum over an empty dim)
+        if (nonfinite && nonfinite_host)
+            DNP_CHECK_HIP(hipMemcpyAsync(nonfinite_host, nonfinite, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
         if (!accumulate) {
             ReduceArgs<F> ra{};
             ra.partial = nullptr; ra.T = T; ra.tgt_idx = tgt_idx; ra.out = out; ra.ld_out = ld_out;

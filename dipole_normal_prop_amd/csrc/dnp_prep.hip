@@ -116,6 +116,33 @@ __global__ __launch_bounds__(256) void patch_pca_kernel(const F* __restrict__ pt
 // ---- greedy loop on W: one wavefront, lane l owns patches l, l+64, ... (EPL per lane) -------------------------
 // I_j = sum_{k visited} sigma_k W[k][j]; pick the first maximum of |I_j| over the unvisited patches in patch
 // order (torch.argmax over the reference's `remaining` list, which stays in patch order), flip when I_j < 0.
+// A step is a dependent chain (argmax -> row fetch -> add), so its latency is the whole cost: the wave argmax
+// runs its four intra-row rounds on DPP (quad_perm / row_half_mirror / row_mirror: register-to-register) and only
+// the two cross-row rounds through ds_bpermute; the winner's signed value is fetched with v_readlane.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)dpp_i32<CTRL>((int)(unsigned)(b & 0xffffffffull));
+    const unsigned hi = (unsigned)dpp_i32<CTRL>((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void take_better(double& bv, int& bj, double ov, int oj) {
+    if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+}
+// (bv, bj) -> the wave's (max bv, smallest bj among equals) in every lane
+__device__ __forceinline__ void wave_argmax(double& bv, int& bj) {
+    take_better(bv, bj, dpp_f64<0xB1>(bv), dpp_i32<0xB1>(bj));     // quad_perm [1,0,3,2]: lane ^ 1
+    take_better(bv, bj, dpp_f64<0x4E>(bv), dpp_i32<0x4E>(bj));     // quad_perm [2,3,0,1]: lane ^ 2
+    take_better(bv, bj, dpp_f64<0x141>(bv), dpp_i32<0x141>(bj));   // row_half_mirror: quads of an 8-lane half swap
+    take_better(bv, bj, dpp_f64<0x140>(bv), dpp_i32<0x140>(bj));   // row_mirror: halves of a 16-lane row swap
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) take_better(bv, bj, __shfl_xor(bv, off, 64), __shfl_xor(bj, off, 64));
+}
+
 template <int EPL>
 __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restrict__ W, int P,
                                                           const int64_t* __restrict__ start_ptr,
@@ -146,21 +173,24 @@ __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restri
         }
         if (step + 1 == P) break;
         // first maximum of |I_j| in patch order; a NaN counts as the maximum, as in torch.argmax
-        double bv = -1.0, bi = 0.0;
+        double bv = -1.0;
         int bj = 0x7fffffff;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {                  // ascending j within the lane
             double a = fabs(inter[e]);
             if (a != a) a = __builtin_huge_val();
-            if (!((visited >> e) & 1ull) && a > bv) { bv = a; bj = e * 64 + lane; bi = inter[e]; }
+            if (!((visited >> e) & 1ull) && a > bv) { bv = a; bj = e * 64 + lane; }
         }
+        wave_argmax(bv, bj);
+        cur = __builtin_amdgcn_readfirstlane(bj);        // wave-uniform
+        // the winner's signed interaction lives in lane cur & 63, entry cur >> 6
+        double mine = 0.0;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ov = __shfl_xor(bv, off, 64), oi = __shfl_xor(bi, off, 64);
-            const int oj = __shfl_xor(bj, off, 64);
-            if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; bi = oi; }
-        }
-        cur = bj;                                        // wave-uniform after the butterfly
+        for (int e = 0; e < EPL; ++e) mine = (e == (cur >> 6)) ? inter[e] : mine;
+        const unsigned long long mb = __builtin_bit_cast(unsigned long long, mine);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mb & 0xffffffffull), cur & 63);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mb >> 32), cur & 63);
+        const double bi = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
         s = (bi < 0.0) ? -1.0 : 1.0;                     // `if interaction[max] < 0: flip`
         if (lane == 0) chosen[step] = bi;
     }
@@ -169,6 +199,41 @@ __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restri
         const int j = e * 64 + lane;
         if (j < P) sigma[j] = ((negative >> e) & 1ull) ? -1.0 : 1.0;
     }
+}
+
+// ---- the tail of the batched patch drivers in ONE launch (field_utils.py:322-323 flips, :337-342 diffuse sign pass,
+// :344-346 weight un-scaling), on the patch-sorted working cloud: for sorted row t
+//   n = work[t].n * sigma[patch(t)]                                    (patch(t) < 0: not in any patch, untouched)
+//   diffuse and listed[patch(t)]:  n *= ((float)E64[t] . n > 0) ? +1 : -1     (fp32 products, summed in order)
+//   weights:  n /= w[t]
+//   out[perm[t]] (row stride ld_out, columns 3..5) = n        - the caller's point order and tensor
+template <typename OUT>
+__global__ __launch_bounds__(256) void patch_finish_kernel(const float* __restrict__ work, int64_t ld, int64_t N,
+                                                           const int64_t* __restrict__ point_patch,
+                                                           const double* __restrict__ sigma,
+                                                           const double* __restrict__ E64,
+                                                           const unsigned char* __restrict__ listed,
+                                                           const float* __restrict__ weights,
+                                                           const int64_t* __restrict__ perm, OUT* __restrict__ out,
+                                                           int64_t ld_out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    const float* r = work + t * ld;
+    float n0 = r[3], n1 = r[4], n2 = r[5];
+    const int64_t k = point_patch[t];
+    if (k >= 0) {
+        const float sg = (float)sigma[k];
+        n0 *= sg; n1 *= sg; n2 *= sg;
+        if (E64 && (!listed || listed[k])) {
+            const float e0 = (float)E64[t * 3 + 0], e1 = (float)E64[t * 3 + 1], e2 = (float)E64[t * 3 + 2];
+            const float dot = __fadd_rn(__fadd_rn(__fmul_rn(e0, n0), __fmul_rn(e1, n1)), __fmul_rn(e2, n2));
+            const float s = dot > 0.f ? 1.f : -1.f;
+            n0 *= s; n1 *= s; n2 *= s;
+        }
+    }
+    if (weights) { const float w = weights[t]; n0 = n0 / w; n1 = n1 / w; n2 = n2 / w; }
+    OUT* o = out + (perm ? perm[t] : t) * ld_out;
+    o[3] = (OUT)n0; o[4] = (OUT)n1; o[5] = (OUT)n2;
 }
 
 // E64[t][c] (+)= sum_k sigma[k] * dE[k][t][c] over the K slabs held here, accumulated in fp64 in slab order.
@@ -264,6 +329,25 @@ int dnp_combine_signed_f32(const float* dE, int64_t K, int64_t N, const double* 
     const int64_t N3 = N * 3;
     hipLaunchKernelGGL(combine_signed_kernel, dim3((unsigned)ceil_div(N3, 256)), dim3(256), 0, (hipStream_t)stream,
                        dE, K, N3, sigma ? sigma + p_lo : nullptr, E, accumulate);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+int dnp_patch_finish_f32(const float* work, int64_t ld_work, int64_t N, const int64_t* point_patch,
+                         const double* sigma, const double* E64, const unsigned char* listed, const float* weights,
+                         const int64_t* perm, void* out, int64_t ld_out, int out_is_f64, void* stream) {
+    clear_error();
+    DNP_REQUIRE(N >= 0, "negative N");
+    if (N == 0) return DNP_OK;
+    DNP_REQUIRE(work && point_patch && sigma && out, "NULL pointer");
+    DNP_REQUIRE(ld_work >= 6 && ld_out >= 6, "row stride < 6");
+    const dim3 grid((unsigned)ceil_div(N, 256));
+    if (out_is_f64)
+        hipLaunchKernelGGL((patch_finish_kernel<double>), grid, dim3(256), 0, (hipStream_t)stream, work, ld_work, N,
+                           point_patch, sigma, E64, listed, weights, perm, (double*)out, ld_out);
+    else
+        hipLaunchKernelGGL((patch_finish_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, work, ld_work, N,
+                           point_patch, sigma, E64, listed, weights, perm, (float*)out, ld_out);
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
 }

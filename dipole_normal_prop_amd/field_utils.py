@@ -223,7 +223,7 @@ def _field_like(kind, sources, means, eps, recursive, max_pts):
     T = tgt.shape[0]
     out = torch.empty((T, 3) if kind == "field" else (T,), dtype=wd, device=dev)
     if T > 0:
-        if kind == "field":
+        if kind == "field" and src.shape[0] > 0:
             # the reference prints (never raises) when a leaf produced Inf/NaN, then zeroes them
             st = _warn_state(dev)
             st.drain()
@@ -405,17 +405,19 @@ def _flip_by_listing(work: torch.Tensor, neg: torch.Tensor, lists_csr) -> None:
     work[:, 3:] = work[:, 3:] * s[:, None]
 
 
-def _diffuse_sign_pass(work: torch.Tensor, E: torch.Tensor, index_lists) -> None:
+def _diffuse_sign_pass(work: torch.Tensor, E: torch.Tensor, index_lists, listed: Optional[torch.Tensor] = None) -> None:
     """sign = (E.n > 0) * 2 - 1 applied to the normals of every listed point (field_utils.py:337-342,
     :267-271), all lists at once.  A point listed twice gets the same result as in the reference's loop:
-    after the first visit E.n > 0, so the second visit multiplies by +1."""
-    if len(index_lists) == 0:
-        return
-    listed = torch.zeros(work.shape[0], dtype=torch.bool, device=work.device)
-    if isinstance(index_lists, util.PatchList):
-        listed[index_lists.flat.to(work.device)] = True
-    else:
-        listed[torch.cat([p.to(work.device) for p in index_lists])] = True
+    after the first visit E.n > 0, so the second visit multiplies by +1.  `listed` = a ready-made bool mask of
+    the listed points (the drivers derive it from the patch ids when the lists are the patches themselves)."""
+    if listed is None:
+        if len(index_lists) == 0:
+            return
+        listed = torch.zeros(work.shape[0], dtype=torch.bool, device=work.device)
+        if isinstance(index_lists, util.PatchList):
+            listed[index_lists.flat.to(work.device)] = True
+        else:
+            listed[torch.cat([p.to(work.device) for p in index_lists])] = True
     pos = (E * work[:, 3:]).sum(dim=-1) > 0
     s = torch.where(listed & ~pos, -1.0, 1.0).to(work.dtype)
     work[:, 3:] = work[:, 3:] * s[:, None]
@@ -520,29 +522,88 @@ def _greedy_on_device(W: torch.Tensor, start_t: torch.Tensor):
     return order, sigma, chosen
 
 
+class _Batched:
+    __slots__ = ("order", "sigma", "chosen", "Es", "perm", "swork", "sorted_patch")
+
+    def __init__(self, order, sigma, chosen, Es, perm, swork, sorted_patch):
+        self.order, self.sigma, self.chosen, self.Es = order, sigma, chosen, Es
+        self.perm, self.swork, self.sorted_patch = perm, swork, sorted_patch
+
+    @property
+    def point_patch(self) -> torch.Tensor:
+        """patch id of every point in the caller's row order (-1 = in no patch)."""
+        out = torch.empty_like(self.sorted_patch)
+        out[self.perm] = self.sorted_patch
+        return out
+
+    def field(self) -> Optional[torch.Tensor]:
+        """E64 in the caller's row order."""
+        if self.Es is None:
+            return None
+        E = torch.empty_like(self.Es)
+        E[self.perm] = self.Es
+        return E
+
+
+def _finish_batched(pts: torch.Tensor, st: "_Batched", diffuse: bool, listed_patches, w) -> None:
+    """The tail of a batched patch driver in one launch (dnp_patch_finish_f32): patch flips, diffuse sign pass on
+    the listed patches, weight un-scaling, and the store into the caller's tensor (any float dtype/device)."""
+    lib = _lib.require_device()
+    dev = st.swork.device
+    N = st.swork.shape[0]
+    direct = pts.is_cuda and pts.device == dev and pts.dtype in (torch.float32, torch.float64) and pts.stride(1) == 1
+    out = pts if direct else torch.empty((N, 6), dtype=torch.float32, device=dev)
+    w_sorted = None if w is None else w[st.perm].contiguous()
+    with _on_device(dev):
+        rc = lib.dnp_patch_finish_f32(_lib.ptr(st.swork), st.swork.stride(0), N, _lib.ptr(st.sorted_patch),
+                                      _lib.ptr(st.sigma), _lib.ptr(st.Es if diffuse else None), _lib.ptr(listed_patches),
+                                      _lib.ptr(w_sorted), _lib.ptr(st.perm), _lib.ptr(out), out.stride(0),
+                                      int(out.dtype == torch.float64), _lib.current_stream())
+    _lib.check(rc)
+    if not direct:
+        pts[:, 3:] = out[:, 3:].to(device=pts.device, dtype=pts.dtype)
+
+
+def _listed_patches(patches, all_patches, dev) -> Optional[torch.Tensor]:
+    """uint8[P] flags of the filtered patches [(i, idx)] when every idx IS all_patches[i] (what the callers pass:
+    inference_utils.fix_n_filter returns the patch objects it was given); None when the lists are something else."""
+    if any(not (0 <= i < len(all_patches)) or patch is not all_patches[i] for i, patch in patches):
+        return None
+    flags = np.zeros(len(all_patches), dtype=np.uint8)
+    if len(patches):
+        flags[[i for i, _ in patches]] = 1
+    return torch.from_numpy(flags).to(dev)
+
+
 def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tensor, diffuse: bool,
                                eps: float = 1e-5, want_E: bool = True, shard=None):
     """Core of the batched drivers on a device cloud `work[N,6]` (normals already weight-scaled); everything
     stays on the device - no host synchronisation between the launches.
 
-    Returns (order, sigma, chosen, E64, point_patch): device tensors; E64[N,3] is this rank's part of the
-    accumulated field of the diffuse form (fp64 sum of the sigma-signed fp32 slabs, in the caller's point
-    order; None unless want_E and diffuse), point_patch[N] the patch id per point (-1 = in no patch).
+    Returns a _Batched: device tensors order / sigma / chosen; Es[N,3] = this rank's part of the accumulated
+    field of the diffuse form (fp64 sum of the sigma-signed fp32 slabs) in PATCH-SORTED row order (None unless
+    want_E and diffuse); perm (sorted row -> caller's row), the sorted working cloud and patch ids, and
+
     `shard` = (rank, world, gather_fn): patches are split over ranks in contiguous size-balanced blocks, each
     rank computes its slabs and W rows, gather_fn(rows, bounds) returns the full W on every rank."""
     dev = work.device
     N = work.shape[0]
     off, idx, sizes = util.patch_csr(patches, dev)
     P = len(sizes)
-    orig_point_patch = _point_patch_ids(idx, sizes, N)
     # data layout for the kernels: the cloud sorted by patch (points in no patch last), so that a patch
     # is a contiguous row range - sources stream linearly and K3 reads its slab rows coalesced
-    if int(sizes.sum()) == N:
+    covered = int(sizes.sum())
+    point_patch = torch.repeat_interleave(torch.arange(P, device=dev), torch.from_numpy(sizes).to(dev),
+                                          output_size=covered)
+    if covered == N:
         perm = idx
     else:
-        perm = torch.cat([idx, torch.nonzero(orig_point_patch < 0).flatten()])
+        seen = torch.zeros(N, dtype=torch.bool, device=dev)
+        seen[idx] = True
+        loose = torch.nonzero(~seen).flatten()
+        perm = torch.cat([idx, loose])
+        point_patch = torch.cat([point_patch, torch.full((loose.shape[0],), -1, dtype=torch.int64, device=dev)])
     swork = work[perm].contiguous()
-    point_patch = orig_point_patch[perm].contiguous()
 
     rank, world, gather = (0, 1, None) if shard is None else shard
     # contiguous blocks of patches per rank, balanced by pair count |patch| * N
@@ -583,9 +644,8 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
                 dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps)
                 _combine_signed(dE, sigma, b0, Es, True)
                 del dE
-        E64 = torch.empty_like(Es)
-        E64[perm] = Es
-    return order, sigma, chosen, E64, orig_point_patch
+        E64 = Es
+    return _Batched(order, sigma, chosen, E64, perm, swork, point_patch)
 
 
 def _balanced_blocks(sizes: np.ndarray, world: int) -> np.ndarray:
@@ -694,14 +754,21 @@ def strongest_field_propagation(pts, patches, all_patches, diffuse=False, weight
         start_t = _start_tensor(work, all_patches, start_patch)
         mode = PATCH_MODE
         if mode == "auto":
-            mode = "batched" if _disjoint(_csr(all_patches, dev)[1], work.shape[0]) else "sequential"
+            known = isinstance(all_patches, util.PatchList) and all_patches.disjoint
+            mode = "batched" if known or _disjoint(_csr(all_patches, dev)[1], work.shape[0]) else "sequential"
         if mode == "batched":
-            order, sigma, chosen, E, point_patch = _batched_patch_propagation(work, all_patches, start_t, diffuse)
-            flip = torch.where(point_patch >= 0, sigma[point_patch.clamp(min=0)], 1.0).to(torch.float32)
-            work[:, 3:] = work[:, 3:] * flip[:, None]
-        else:
-            order, sigma, chosen, E = _sequential_patch_propagation(work, list(all_patches), int(start_t.item()),
-                                                                    diffuse)
+            st = _batched_patch_propagation(work, all_patches, start_t, diffuse)
+            listed = _listed_patches(patches, all_patches, dev) if diffuse else None
+            if not diffuse or listed is not None:
+                _finish_batched(pts, st, diffuse, listed, w)
+            else:                                       # diffuse lists that are not the patches themselves
+                flip = torch.where(st.point_patch >= 0, st.sigma[st.point_patch.clamp(min=0)], 1.0).to(torch.float32)
+                work[:, 3:] = work[:, 3:] * flip[:, None]
+                _diffuse_sign_pass(work, st.field().to(torch.float32), [patch for _, patch in patches])
+                _finish_patch_driver(pts, work, w)
+            _set_trace("patches", order=st.order, sigma=st.sigma, chosen=st.chosen, start=start_t)
+            return
+        order, sigma, chosen, E = _sequential_patch_propagation(work, list(all_patches), int(start_t.item()), diffuse)
         if diffuse:
             _diffuse_sign_pass(work, E.to(torch.float32), [patch for _, patch in patches])
         _finish_patch_driver(pts, work, w)
@@ -734,9 +801,10 @@ def strongest_field_propagation_reps(input_pc, reps, diffuse=False, weights=None
         sub_patches = util.PatchList(torch.arange(all_reps.shape[0], device=dev), rep_sizes)
         E = torch.zeros((N, 3), dtype=torch.float32, device=dev)
         if mode == "batched":
-            order, sigma, chosen, E_sub, _ = _batched_patch_propagation(sub, sub_patches, start_t, diffuse)
-            if E_sub is not None:
-                E[all_reps] = E_sub.to(torch.float32)
+            st = _batched_patch_propagation(sub, sub_patches, start_t, diffuse)
+            order, sigma, chosen = st.order, st.sigma, st.chosen
+            if st.Es is not None:
+                E[all_reps] = st.field().to(torch.float32)
             neg = sigma < 0
         else:
             order, sigma, chosen, E_sub = _sequential_patch_propagation(sub, list(sub_patches), int(start_t.item()),

@@ -103,13 +103,15 @@ def sharded_patch_propagation(pts: torch.Tensor, patches, all_patches, diffuse=F
             return
         work, w = fu._prepare_work(pts, weights)
         start_t = agree_on_start(fu._start_tensor(work, all_patches, start_patch))
-        order, sigma, chosen, E, point_patch = fu._batched_patch_propagation(
-            work, all_patches, start_t, diffuse, shard=(rank, size, gather_rows))
-        if diffuse and E is not None:
-            E = reduce_field(E)
-        flip = torch.where(point_patch >= 0, sigma[point_patch.clamp(min=0)], 1.0).to(torch.float32)
-        work[:, 3:] = work[:, 3:] * flip[:, None]
-        if diffuse:
-            fu._diffuse_sign_pass(work, E.to(torch.float32), [patch for _, patch in patches])
-        fu._finish_patch_driver(pts, work, w)
-        fu._set_trace("sharded", order=order, sigma=sigma, chosen=chosen, start=start_t)
+        st = fu._batched_patch_propagation(work, all_patches, start_t, diffuse, shard=(rank, size, gather_rows))
+        if diffuse and st.Es is not None:
+            st.Es = reduce_field(st.Es)                 # patch-sorted rows: the same permutation on every rank
+        listed = fu._listed_patches(patches, all_patches, work.device) if diffuse else None
+        if not diffuse or listed is not None:
+            fu._finish_batched(pts, st, diffuse, listed, w)
+        else:
+            flip = torch.where(st.point_patch >= 0, st.sigma[st.point_patch.clamp(min=0)], 1.0).to(torch.float32)
+            work[:, 3:] = work[:, 3:] * flip[:, None]
+            fu._diffuse_sign_pass(work, st.field().to(torch.float32), [patch for _, patch in patches])
+            fu._finish_patch_driver(pts, work, w)
+        fu._set_trace("sharded", order=st.order, sigma=st.sigma, chosen=st.chosen, start=start_t)

@@ -157,9 +157,10 @@ class PatchList(list):
     `flat`, so drivers handed a PatchList need neither a torch.cat of hundreds of small tensors nor a device
     round trip to learn the sizes."""
 
-    def __init__(self, flat: torch.Tensor, sizes):
+    def __init__(self, flat: torch.Tensor, sizes, disjoint: bool = False):
         self.flat = flat
         self.sizes = [int(n) for n in sizes]
+        self.disjoint = bool(disjoint)        # True when the producer guarantees no point is listed twice
         super().__init__(torch.split(flat, self.sizes) if len(self.sizes) else [])
 
 
@@ -223,7 +224,7 @@ def _divide_pc(pc_in: torch.Tensor, n_part: int, ranges=(-1.5, 1.5), min_patch: 
     order, keys, counts = _voxel_cells(pc_in, n_part, ranges)
     if keys.size == 0:
         return [], []
-    return PatchList(order, counts), [tuple(int(v) for v in row) for row in _keys_to_ijk(keys, n_part)]
+    return PatchList(order, counts, disjoint=True), [tuple(int(v) for v in row) for row in _keys_to_ijk(keys, n_part)]
 
 
 def merge_cells(ijk: np.ndarray, sizes: np.ndarray, min_patch: int):
@@ -282,7 +283,7 @@ def divide_pc(pc_in: torch.Tensor, n_part: int, ranges=(-1.5, 1.5), min_patch: i
     shift = torch.from_numpy((starts[seq] - out_first).astype(np.int64)).to(order.device)
     reps = torch.from_numpy(sz.astype(np.int64)).to(order.device)
     pos = torch.arange(total, device=order.device) + torch.repeat_interleave(shift, reps, output_size=total)
-    return PatchList(order[pos], sizes)
+    return PatchList(order[pos], sizes, disjoint=True)        # a partition: every point in at most one patch
 
 
 def pca_eigen_values(x: torch.Tensor):

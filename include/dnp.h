@@ -206,6 +206,20 @@ int dnp_patch_greedy(const double* W, int64_t P, const int64_t* start, int64_t* 
 int dnp_combine_signed_f32(const float* dE, int64_t K, int64_t N, const double* sigma, int64_t P, int64_t p_lo,
                            double* E, int accumulate, void* stream);
 
+/* ---- tail of the batched patch drivers in one launch (field_utils.py:322-323, :337-342, :344-346) ----------
+ *
+ * On the patch-sorted working cloud work[N, >=6] (fp32, normals possibly weight-scaled), for sorted row t:
+ *   n = work[t].n * sigma[point_patch[t]]                       (point_patch[t] < 0: in no patch, not flipped)
+ *   E64 != NULL and (listed == NULL or listed[patch]):  n *= ((float)E64[t] . n > 0) ? +1 : -1   (the diffuse pass)
+ *   weights != NULL:  n /= weights[t]                                                  (sorted order, clamped)
+ *   out[perm ? perm[t] : t][3..5] = n     out is the caller's cloud (float or double rows of stride ld_out)
+ * E64 is [N,3] doubles in sorted order (dnp_combine_signed_f32), listed [P] bytes, perm [N] the sorted -> caller
+ * row map.  Everything on the device.
+ */
+int dnp_patch_finish_f32(const float* work, int64_t ld_work, int64_t N, const int64_t* point_patch,
+                         const double* sigma, const double* E64, const unsigned char* listed, const float* weights,
+                         const int64_t* perm, void* out, int64_t ld_out, int out_is_f64, void* stream);
+
 /* ---- merge of small voxel cells  (util.merge_nodes, util.py:448-492) - HOST function, host pointers ----
  *
  * cell_ijk[C,3] (int32 voxel coordinates in [0, 2^20)) and cell_size[C] describe the non-empty cells of the

@@ -18,7 +18,7 @@ from oracle import dipole_oracle as O
 
 class OracleStandIn:
     """CPU stand-ins for the device entry wrappers (dnp_patch_fields_f32 / dnp_interactions_f32 /
-    dnp_patch_greedy / dnp_combine_signed_f32).  The worker processes of this test patch them into field_utils
+    dnp_patch_greedy / dnp_combine_signed_f32 / dnp_patch_finish_f32).  The worker processes of this test patch them into field_utils
     so that the partition / gather / reduce plumbing of the N>1 path can run without a GPU; the product code
     itself has no such switch."""
 
@@ -46,6 +46,19 @@ class OracleStandIn:
         from dipole_normal_prop_amd import field_utils as fu
         order, sigma, chosen = fu.greedy_order_from_interactions(W.numpy(), int(start_t[0]))
         return torch.from_numpy(order), torch.from_numpy(sigma), torch.from_numpy(chosen)
+
+    @staticmethod
+    def finish(pts, st, diffuse, listed, w):
+        n = st.swork[:, 3:].clone()
+        in_patch = st.sorted_patch >= 0
+        n[in_patch] = n[in_patch] * st.sigma[st.sorted_patch[in_patch]].float()[:, None]
+        if diffuse:
+            dot = (st.Es.float() * n).sum(dim=-1)
+            flip = in_patch & (dot <= 0)
+            if listed is not None:
+                flip &= listed.bool()[st.sorted_patch.clamp(min=0)]
+            n[flip] = -n[flip]
+        pts[st.perm, 3:] = n.to(pts.dtype)
 
     @staticmethod
     def combine_signed(dE, sigma, p_lo, E64, accumulate):
@@ -76,6 +89,7 @@ def _worker(rank, world, port, start, q):
         from dipole_normal_prop_amd import field_utils as fu
         fu._patch_slabs, fu._interaction_rows = OracleStandIn.slabs, OracleStandIn.interactions
         fu._greedy_on_device, fu._combine_signed = OracleStandIn.greedy, OracleStandIn.combine_signed
+        fu._finish_batched = OracleStandIn.finish
         fu._prepare_work = lambda p, w: (p.detach().clone().float(), None)       # CPU working copy (no weights here)
         parallel.sharded_patch_propagation(pts, list(enumerate(patches)), patches, diffuse=True, start_patch=start)
         tr = fu.last_trace("sharded")

@@ -342,8 +342,12 @@ def test_G6_patch_propagation(dev, tag, mode, monkeypatch):
         pytest.skip("sequential form is covered on two representative cases")
     monkeypatch.setattr(fu, "PATCH_MODE", mode)
     pts = cloud.clone().to(dev)
-    ret = fu.strongest_field_propagation(pts, [(i, p.to(dev)) for i, p in patches], [p.to(dev) for p in allp],
-                                         diffuse=diffuse, weights=None if w is None else w.to(dev))
+    allp_dev = [p.to(dev) for p in allp]
+    if tag.startswith("pf"):      # the filtered lists ARE the patch objects (what the callers pass): fused tail kernel
+        filt = [(i, allp_dev[i]) for i, _ in patches]
+    else:                         # separate index tensors: the general (torch) tail
+        filt = [(i, p.to(dev)) for i, p in patches]
+    ret = fu.strongest_field_propagation(pts, filt, allp_dev, diffuse=diffuse, weights=None if w is None else w.to(dev))
     assert ret is None                                               # in place, returns None
     tr = fu.last_trace("patches")
     assert tr["start"] == int(g[f"order_{tag}"][0])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for bench.py (run on the GPU box through gpurun): kernel-trace stats, then the
 # PMC passes in runs of their own (never combined with a trace domain other than --kernel-trace).
-set -e
+set +e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
