@@ -16,16 +16,19 @@
 
 namespace dnp {
 
-// shortest chunk a leaf is cut into: 64 sources for tiny source sets (latency bound: more, shorter workgroups),
-// growing to 512 so that large source sets are not shredded into hundreds of chunks per leaf
+// shortest chunk a leaf is cut into: 64 sources, growing to 512 for very large source sets (S / 512),
+// so that the by-value chunk table (512 entries) always suffices for one round per ~262 000 sources
 #ifndef DNP_MINCHUNK_CAP
 #define DNP_MINCHUNK_CAP 512
 #endif
-static inline int64_t min_chunk(int64_t S) { const int64_t m = S / 64; return m < 64 ? 64 : (m > DNP_MINCHUNK_CAP ? DNP_MINCHUNK_CAP : m); }
+#ifndef DNP_MINCHUNK_DIV
+#define DNP_MINCHUNK_DIV 512
+#endif
+static inline int64_t min_chunk(int64_t S) { const int64_t m = S / DNP_MINCHUNK_DIV; return m < 64 ? 64 : (m > DNP_MINCHUNK_CAP ? DNP_MINCHUNK_CAP : m); }
 // targets per lane for large target sets: 2 in the scalar-unit kernel (contiguous sources), 4 in the LDS kernel
 // (gathered sources; swept: 4 x 2 accumulator sets); 1 for small target sets in both
 constexpr int kKTScalar = 2, kKTLds = 4;
-constexpr int64_t kTilesForLarge = 64;     // ... used once that still leaves >= 64 target tiles
+constexpr int64_t kTilesForLarge = 16;     // ... used once that still leaves >= 16 target tiles (T >= 8192 / 16384)
 constexpr size_t kSlabCap = (size_t)1 << 30;  // bytes of partial slab per round
 struct Plan {
     // one entry per round; every round is a run of whole leaves
@@ -53,15 +56,21 @@ static void split_leaves(int64_t lo, int64_t hi, int64_t max_pts, std::vector<in
 #define DNP_K1_FAR 1
 #endif
 
-// Number of source chunks for one launch: enough that the launch has ~kWantBlocks workgroups (about four
-// resident sets of the scalar kernel).  Measured on MI355X (tools/gpu_k1_ab.py, profiles/r02_k1_planning.txt): more,
-// shorter chunks beat a plan that fills the chip exactly once (30k x 30k: 517 us with 64-200 chunks against 598 us
-// with 17), and the chunk count hardly matters beyond that; the fp64 partial slab (24 B per target and chunk) is
-// written once and read once and stays below 3 % of the time.
-constexpr int64_t kWantBlocks = 8192;
-static int64_t choose_chunks(int64_t S, int64_t T, int64_t t_tiles, int kt, int64_t n_leaves, int64_t cap) {
-    (void)S; (void)T; (void)kt; (void)cap;
-    int64_t want = ceil_div(kWantBlocks, t_tiles);
+// Number of source chunks for one launch, from the sweep in profiles/r02_k1_planning.txt (tools/gpu_k1_ab.py, MI355X):
+// short chunks win - ~256 sources per chunk, and at least ~4096 workgroups when the target set is small - as long
+// as the fp64 partial slab (24 B per target and chunk, written once and read once) stays around 300 MB:
+//   fandisk 11 031^2: 93-186 chunks 90 us (32 chunks 106 us);   30 000^2: 186 chunks 476 us (46 chunks 515 us);
+//   100 000^2: 128 chunks 4.82 ms (42 chunks 5.01 ms, the 1 GB slab of 390 chunks would cost 0.4 ms).
+// make_plan clips the answer by the shortest chunk it allows and by the by-value chunk table.
+constexpr int64_t kChunkSources = 256, kWantBlocks = 4096, kShortestUseful = 128;
+constexpr size_t kSlabTarget = (size_t)320 << 20;
+static int64_t choose_chunks(int64_t S, int64_t T, int64_t t_tiles, int64_t n_leaves, int nc) {
+    int64_t want = S / kChunkSources;
+    int64_t fill = ceil_div(kWantBlocks, t_tiles);          // small target sets: more workgroups, but not chunks so
+    if (fill > S / kShortestUseful) fill = S / kShortestUseful;   // short that the workgroup prologue dominates
+    if (want < fill) want = fill;
+    const int64_t slab = (int64_t)(kSlabTarget / ((size_t)(T > 0 ? T : 1) * nc * sizeof(double)));
+    if (want > slab) want = slab;
     if (want < n_leaves) want = n_leaves;
     return want;
 }
@@ -83,7 +92,7 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
     int64_t cap = (int64_t)(kSlabCap / ((size_t)(T > 0 ? T : 1) * nc * elem));
     if (cap > kMaxChunks) cap = kMaxChunks;
     if (cap < 1) cap = 1;
-    int64_t want = choose_chunks(S, T, t_tiles, plan.kt, n_leaves, cap >= n_leaves ? cap : kMaxChunks);
+    int64_t want = choose_chunks(S, T, t_tiles, n_leaves, nc);
 #ifdef DNP_FORCE_CHUNKS   // planning experiments only
     want = DNP_FORCE_CHUNKS;
 #endif
@@ -226,7 +235,14 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
     }
 
     // contiguous source rows go through the scalar unit, gathered rows through LDS (pair_kernel.h)
-    const bool scalar_kernel = (src_idx == nullptr);
+#ifndef DNP_K1_FORCE_LDS   // A/B builds only
+#define DNP_K1_FORCE_LDS 0
+#endif
+    // Small problems are latency bound and the LDS kernel's cooperative staging wins there (fandisk 11 031^2: 84 us
+    // against 95 us, 3000^2: 20 against 29 us); from ~5 10^8 pairs on the scalar kernel is level or ahead
+    // (30 000^2: 473 against 496 us) and is the one that can take the far-field chain on sorted clouds
+    // (profiles/r02_k1_planning.txt).
+    const bool scalar_kernel = (src_idx == nullptr) && !DNP_K1_FORCE_LDS && (double)S * (double)T >= 5e8;
     const Plan plan = make_plan(S, T, max_pts, NC, sizeof(double), scalar_kernel);
     const size_t need = plan_workspace(plan, T, NC, sizeof(double));
     if (!workspace || workspace_bytes < need) {
@@ -248,15 +264,24 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
         const bool direct = plan.rounds.size() == 1 && n_chunks == 1;
         pa.out = direct ? out : nullptr; pa.ld_out = ld_out; pa.out_scatter = out_scatter; pa.accumulate = accumulate;
         pa.nonfinite = nonfinite;
-        pa.far_d2 = eps > F(0) ? (F)pow((double)eps / kFarRatio, 2.0 / 3.0) : F(0);
+        // the far-field chain only pays for spatially sorted clouds; its per-workgroup set-up (box scan + barrier) is
+        // noise for big problems and a measurable 5-10 % for small ones (fandisk): off below 10^9 pairs
+        pa.far_d2 = (eps > F(0) && (double)S * (double)T >= 1e9) ? (F)pow((double)eps / kFarRatio, 2.0 / 3.0) : F(0);
         for (int i = 0; i <= n_chunks; ++i) pa.chunk_off[i] = r.chunk_off[i];
         const dim3 grid((unsigned)t_tiles, (unsigned)n_chunks);
         // eps > 0 (what every caller of the reference passes): the short chain; otherwise the explicit one
         const int variant = (MODE != kField) ? kFast : (eps > F(0) ? kFast : (eps == F(0) ? kNanCoinc : kRobust));
 #define DNP_LAUNCH_PAIR(KT, V) \
     hipLaunchKernelGGL((pair_kernel<F, double, MODE, KT, V>), grid, dim3(kBlock), 0, stream, pa)
-#define DNP_LAUNCH_SCALAR(KT, V) \
-    hipLaunchKernelGGL((pair_kernel_scalar<F, double, MODE, KT, V, (sizeof(F) == 4 && DNP_K1_FAR)>), grid, dim3(kBlock), 0, stream, pa)
+#define DNP_LAUNCH_SCALAR(KT, V)                                                                                  \
+    do {                                                                                                          \
+        if (sizeof(F) == 4 && DNP_K1_FAR && pa.far_d2 > F(0))                                                     \
+            hipLaunchKernelGGL((pair_kernel_scalar<F, double, MODE, KT, V, (sizeof(F) == 4 && DNP_K1_FAR)>), grid, \
+                               dim3(kBlock), 0, stream, pa);                                                      \
+        else                                                                                                      \
+            hipLaunchKernelGGL((pair_kernel_scalar<F, double, MODE, KT, V, false>), grid, dim3(kBlock), 0, stream, \
+                               pa);                                                                               \
+    } while (0)
         if (scalar_kernel) {
             if (plan.kt == kKTScalar) {
                 if (variant == kFast) DNP_LAUNCH_SCALAR(kKTScalar, kFast);

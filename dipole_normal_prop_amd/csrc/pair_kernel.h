@@ -463,7 +463,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
     const int64_t ld = a.ld_src;
 
     bool far_chunk = false;
-    if (kFarPath) {
+    if (kFarPath && a.far_d2 > F(0)) {     // far_d2 <= 0: the launcher switched the far machinery off (small problems)
         // box of the chunk's sources (workgroup-cooperative) and of this wave's targets
         F lo[3] = {M::kHuge, M::kHuge, M::kHuge}, hi[3] = {-M::kHuge, -M::kHuge, -M::kHuge};
         for (int64_t q = s_begin + tid; q < s_end; q += kBlock) {
@@ -523,11 +523,20 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
             for (int u = 0; u < kSets; ++u)
 #pragma unroll
                 for (int k = 0; k < KT; ++k) P[u][k] = F(0);
+            for (; s + kSets <= run_end; s += kSets) {
+#pragma unroll
+                for (int u = 0; u < kSets; ++u) {
+                    const F* p = src + (sidx ? sidx[s + u] : s + u) * ld;
+                    const F sx = p[0], sy = p[1], sz = p[2], px = p[3], py = p[4], pz = p[5];
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) pair_potential<F>(sx, sy, sz, px, py, pz, tx[k], ty[k], tz[k], P[u][k]);
+                }
+            }
             for (; s < run_end; ++s) {
                 const F* p = src + (sidx ? sidx[s] : s) * ld;
                 const F sx = p[0], sy = p[1], sz = p[2], px = p[3], py = p[4], pz = p[5];
 #pragma unroll
-                for (int k = 0; k < KT; ++k) pair_potential<F>(sx, sy, sz, px, py, pz, tx[k], ty[k], tz[k], P[s & (kSets - 1)][k]);
+                for (int k = 0; k < KT; ++k) pair_potential<F>(sx, sy, sz, px, py, pz, tx[k], ty[k], tz[k], P[0][k]);
             }
 #pragma unroll
             for (int k = 0; k < KT; ++k)
