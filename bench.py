@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the other_configs legs (profiling runs: only the headline kernels in the trace)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -282,11 +284,15 @@ def main():
                                       "sign-scrambled, seed 0), all per-patch fields + interaction matrix (BASELINE "
                                       "config 4)", "points": N_POINTS,
                           "patches": N_PATCHES, "pairs_per_step": pairs_total,
-                          "parallelism": f"patch-sharded x{world}, RCCL all-gather of W rows"},
+                          "parallelism": f"patch-sharded x{world}, " + ("RCCL" if backend == "nccl" else backend) +
+                                         " all-gather of W rows"},
                "roofline": roofline, "hbm": hbm, "signs_ok": signs_ok}
         if fake > 1 and world == 1:
             out["fake_world"] = fake          # NOT a measurement of `fake` GPUs: one rank's share on one GPU
-        if world == 1 and not (fake > 1):
+        if world > 1 and backend != "nccl":
+            out["rehearsal"] = (f"{backend} collectives; ranks may share a GPU (device_count "
+                                f"{torch.cuda.device_count()}): a functional rehearsal of the N>1 path, not a scaling number")
+        if world == 1 and not (fake > 1) and not args.headline_only:
             ranges = util.PatchList(torch.arange(N_POINTS, device=dev), sizes, disjoint=True)
             out["other_configs"] = other_configs(dev, fu, util, pts, ranges)
         if world == 1 and not args.no_cpu_baseline:

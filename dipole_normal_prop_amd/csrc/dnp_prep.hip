@@ -148,6 +148,10 @@ __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restri
                                                           const int64_t* __restrict__ start_ptr,
                                                           int64_t* __restrict__ order, double* __restrict__ sigma,
                                                           double* __restrict__ chosen) {
+    // the trace stays in LDS until the end: a global store inside the loop would sit in front of the next row's
+    // loads in the wave's vmcnt queue, and every step would wait for a store round trip to memory
+    __shared__ int order_s[64 * EPL];
+    __shared__ double chosen_s[64 * EPL];
     const int lane = threadIdx.x;
     double inter[EPL];
     unsigned long long visited = 0, negative = 0;        // bit e <-> patch e*64 + lane
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restri
     }
     double s = 1.0;                                       // the start patch is not flipped
     for (int step = 0; step < P; ++step) {
-        if (lane == 0) order[step] = cur;
+        if (lane == 0) order_s[step] = cur;
         if ((cur & 63) == lane) {
             visited |= 1ull << (cur >> 6);
             if (s < 0.0) negative |= 1ull << (cur >> 6);
@@ -192,7 +196,12 @@ __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restri
         const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mb >> 32), cur & 63);
         const double bi = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
         s = (bi < 0.0) ? -1.0 : 1.0;                     // `if interaction[max] < 0: flip`
-        if (lane == 0) chosen[step] = bi;
+        if (lane == 0) chosen_s[step] = bi;
+    }
+    __syncthreads();
+    for (int i = lane; i < P; i += 64) {
+        order[i] = order_s[i];
+        if (i + 1 < P) chosen[i] = chosen_s[i];
     }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {

@@ -30,7 +30,7 @@ __all__ = [
     "self_interaction_all", "random_self_interaction", "reference_field",
     "strongest_field_propagation_reps", "strongest_field_propagation",
     "strongest_field_propagation_points", "xie_field", "xie_intersaction", "xie_distance",
-    "xie_propagation_points_in_order", "last_trace", "torch", "np", "util",
+    "xie_propagation_points_in_order", "xie_propagation_points_onbfstree", "align_votes", "last_trace", "torch", "np", "util",
 ]
 
 # "auto": batched (all per-patch fields in one launch, greedy loop as P x P host arithmetic) when the
@@ -1000,3 +1000,59 @@ def xie_propagation_points_in_order(pts: torch.Tensor, eps, order, diffuse=False
         if diffuse:
             inter = weights @ M.transpose(0, 1)            # interactions[t][i] = sum_j M[i][j] * w[t][j]
         return (inter < 0).to(pts.device)
+
+
+def align_votes(flips: torch.Tensor) -> torch.Tensor:
+    """The vote alignment of field_utils.xie_propagation_points_onbfstree (field_utils.py:693-702), where the
+    reference calls gurobi (MIQP, :620-646) on a problem with one binary variable per visiting order: choose
+    x in {0,1}^T minimising  sum_ij [ H_ij if x_i == x_j else N - H_ij ]  with H_ij the Hamming distance between
+    the flip vectors of orders i and j (cal_w, :674-677; cal_loss, :606-617).  T is a handful (the `times` of the
+    caller, odd), so the optimum is found by enumerating all 2^(T-1) assignments with x_0 = 0 - the objective only
+    depends on which x are equal, so x and its complement tie and x_0 = 0 picks one of the two; further ties go
+    to the smallest assignment in binary order.  flips: [T, N] bool.  Returns x as a [T] bool tensor."""
+    T, N = flips.shape
+    if T > 20:
+        raise ValueError(f"{T} visiting orders: the exhaustive vote is meant for the reference's handful of orders")
+    f = flips.to(torch.float64)
+    H = (f[:, None, :] - f[None, :, :]).abs().sum(dim=-1).cpu().numpy()           # [T, T] Hamming distances
+    best_x, best_cost = 0, None
+    for code in range(1 << max(T - 1, 0)):
+        x = np.array([0] + [(code >> b) & 1 for b in range(T - 1)])
+        same = x[:, None] == x[None, :]
+        cost = float(np.where(same, H, N - H).sum())
+        if best_cost is None or cost < best_cost:
+            best_x, best_cost = x, cost
+    return torch.from_numpy(np.asarray(best_x, dtype=bool)).to(flips.device)
+
+
+def xie_propagation_points_onbfstree(pts: torch.Tensor, eps, diffuse=False, starting_point=0, verbose=False, k=10,
+                                     treshold=0.1, times=1, use_pw=False, knn_mask=-1, C=3):
+    """Propagation along breadth-first routes of the kNN graph with a vote over `times` routes
+    (field_utils.py:657-710): routes start at starting_point and at times-1 further points drawn with
+    np.random.seed(0) / randint as in the reference; every route is propagated in order
+    (xie_propagation_points_in_order: one interaction matrix, one persistent workgroup per route), the routes'
+    flip vectors are aligned (align_votes: the reference's MIQP, solved exactly without gurobi), and a point is
+    flipped when more than half of the aligned routes flip it.  `pts` normals are updated in place; returns the
+    [N] bool tensor of flipped points.  use_pw is accepted and has no effect (as points_weight in the reference)."""
+    assert times % 2 == 1 and times > 0
+    with torch.no_grad():
+        starts = [int(starting_point)]
+        np.random.seed(0)
+        while len(np.unique(starts)) < times:
+            cand = np.random.randint(0, pts.shape[0])
+            if cand not in starts:
+                starts.append(cand)
+        adj, _ = util.knn_graph(pts[:, :3].detach().cpu().numpy(), k, treshold)
+        orders = np.zeros((times, pts.shape[0]), dtype=np.int64)
+        for i in range(times):
+            orders[i] = util.bfs_route(adj, starts[i])
+        flips = xie_propagation_points_in_order(pts.clone(), eps, orders, diffuse, verbose=False, knn_mask=knn_mask,
+                                                C=C)                                   # [times, N]
+        status = align_votes(flips)
+        aligned = flips ^ status[:, None].to(flips.device)
+        cnts = aligned.sum(dim=0)
+        flipped = cnts > times / 2
+        sel = flipped.to(pts.device)
+        pts[sel, 3:] = pts[sel, 3:] * -1
+        _set_trace("bfstree", orders=orders, flips=flips, status=status, starts=np.array(starts))
+        return sel

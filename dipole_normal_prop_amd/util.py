@@ -398,6 +398,58 @@ def estimate_normals(pc: torch.Tensor, max_nn: int = 30) -> torch.Tensor:
     return torch.cat([xyz, normals], dim=1)
 
 
+# ---- kNN graph + breadth-first visiting order (graph.getEMSTfromPC / LinkedListGraph.get_bfs_route) -------------
+def knn_graph(xyz: np.ndarray, k: int = 10, threshold: float = 0.1):
+    """Directed k-nearest-neighbour graph of graph.getEMSTfromPC (graph.py:380-392; despite its name it builds no
+    spanning tree): an edge i -> j for each of i's k nearest neighbours j != i closer than `threshold`.  Returns
+    (adjacency: list of sets of ints, mean distance to the k neighbours).  The adjacency sets are real Python
+    sets filled in neighbour order, because the reference iterates sets of objects hashed by their end point:
+    the same insertion sequence of the same hash values gives the same iteration order, and that order decides
+    the BFS route."""
+    xyz = np.asarray(xyz, dtype=np.float64)
+    try:
+        from sklearn.neighbors import KDTree               # what the reference queries (graph.py:345, :382)
+        dist, idx = KDTree(xyz).query(xyz, k)
+    except ImportError:                                     # same neighbours, ties possibly in another order
+        from scipy.spatial import cKDTree
+        dist, idx = cKDTree(xyz).query(xyz, k)
+        dist, idx = dist.reshape(len(xyz), -1), idx.reshape(len(xyz), -1)
+    adj = [set() for _ in range(len(xyz))]
+    for i in range(len(xyz)):
+        for j in range(idx.shape[1]):
+            if idx[i, j] != i and dist[i, j] < threshold:
+                adj[i].add(int(idx[i, j]))
+    return adj, dist.mean(axis=1)
+
+
+def bfs_route(adj, start: int):
+    """Unweighted breadth-first visiting order from `start` (LinkedListGraph.get_bfs_route, graph.py:293-317):
+    FIFO queue, neighbours in the adjacency set's iteration order; when the queue runs dry before every node
+    is visited, the unvisited node of smallest index seeds the next component."""
+    n = len(adj)
+    visited = np.zeros(n, dtype=bool)
+    route, queue, head, units = [], [int(start)], 0, 1
+    visited[start] = True
+    while head < len(queue):
+        u = queue[head]
+        head += 1
+        route.append(u)
+        for v in adj[u]:
+            if not visited[v]:
+                visited[v] = True
+                queue.append(v)
+        if head == len(queue):
+            if visited.all():
+                break
+            nxt = int(np.flatnonzero(~visited)[0])
+            queue.append(nxt)
+            visited[nxt] = True
+            units += 1
+    if units != 1:
+        print("bfs warning::unit= ", units)
+    return route
+
+
 def timer_factory():
     """A fresh timer class whose instances are `with` blocks printing their wall time; the class
     keeps a running total (print_total_time)."""

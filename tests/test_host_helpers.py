@@ -166,3 +166,27 @@ def test_balanced_blocks():
     for w in (1, 3, 8):
         bb = fu._balanced_blocks(sizes, w)
         assert len(bb) == w + 1 and np.all(np.diff(bb) >= 0) and bb[-1] == 6
+
+
+def test_knn_graph_bfs_routes_and_vote_match_the_reference():
+    """graph.getEMSTfromPC + LinkedListGraph.get_bfs_route (routes), the np.random.seed(0) starting points and the
+    vote alignment of field_utils.xie_propagation_points_onbfstree (field_utils.py:657-710) against GX2, captured
+    from the reference with its gurobi MIQP replaced by exhaustive search (tools/gen_golden.py gx2)."""
+    g = load_golden("GX2_xie_bfstree")
+    pc = g["pc"]
+    adj, mean_k = util.knn_graph(pc[:, :3], 10, 0.1)
+    assert len(adj) == 1000 and mean_k.shape == (1000,)
+    for tag in ("t1_n", "t5_n", "t5_d"):
+        orders = g[f"orders_{tag}"]
+        for row in orders:
+            route = util.bfs_route(adj, int(row[0]))
+            assert np.array_equal(np.array(route), row)
+        status = fu.align_votes(t(g[f"flips_{tag}"]))
+        assert np.array_equal(status.numpy(), g[f"status_{tag}"])
+        aligned = g[f"flips_{tag}"] ^ g[f"status_{tag}"][:, None]
+        assert np.array_equal(aligned.sum(axis=0) > len(orders) / 2, g[f"result_{tag}"])
+    # a vote where two routes are mirror images of the third: they must end up with opposite x
+    a = torch.zeros(3, 50, dtype=torch.bool)
+    a[1] = True
+    a[2, :3] = True
+    assert fu.align_votes(a).tolist() == [False, True, False]

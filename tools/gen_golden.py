@@ -670,6 +670,54 @@ def gw(fu, util):
          short_ack=u8(short.sent[0]), short_reply=u8(short.sent[1]), decoded_xyz=seen["xyz"])
 
 
+def gx2(fu, util):
+    """BFS-route propagation with a vote (field_utils.xie_propagation_points_onbfstree, field_utils.py:657-710)
+    on the 1000-point ok.xyz subsample, times = 1 and 5.  The reference's own graph.getEMSTfromPC /
+    LinkedListGraph.get_bfs_route build the routes; its MIQP (gurobi, absent offline) is replaced IN THE HARNESS by
+    an exhaustive search over the 2^times assignments of the same objective (cal_loss, field_utils.py:606-617),
+    with x[0] = 0 choosing between an optimum and its complement (they tie by construction).  Captured: the
+    starting points, the routes, the per-route flip vectors, the aligned vote and the final flip vector."""
+    import itertools
+    pc = torch.from_numpy(np.load(os.path.join(OUT, "G8_point_propagation.npz"))["pc_sub1000"])
+    seen = {}
+    orig_in_order, orig_miqp = fu.xie_propagation_points_in_order, fu.MIQP
+
+    def rec_in_order(pts, eps, order, *a, **k):
+        seen["orders"] = np.array(order)
+        res = orig_in_order(pts, eps, order, *a, **k)
+        seen["flips"] = res.clone()
+        return res
+
+    def exhaustive(A, B):
+        n = len(A)
+        best, best_cost = None, None
+        for tail in itertools.product((0, 1), repeat=n - 1):
+            x = np.array((0,) + tail[::-1])                      # binary order with x[0] fixed to 0
+            cost = fu.cal_loss(x, A, B)
+            if best_cost is None or cost < best_cost:
+                best, best_cost = x, cost
+        seen["status"] = best.astype(bool)
+        return best.astype(float)
+
+    fu.xie_propagation_points_in_order, fu.MIQP = rec_in_order, exhaustive
+    out = dict(pc=pc)
+    try:
+        for times, diffuse in ((1, False), (5, False), (5, True)):
+            pts = pc.clone()
+            res = fu.xie_propagation_points_onbfstree(pts, 0.1, diffuse=diffuse, starting_point=0, k=10, treshold=0.1,
+                                                      times=times, knn_mask=-1, C=3)
+            tag = f"t{times}_{'d' if diffuse else 'n'}"
+            out[f"orders_{tag}"] = seen["orders"]
+            out[f"flips_{tag}"] = seen["flips"]
+            out[f"status_{tag}"] = seen["status"]
+            out[f"result_{tag}"] = res
+            out[f"normals_{tag}"] = pts[:, 3:]
+            print(f"  GX2 {tag}: flipped {int(res.sum())}, status {seen['status'].astype(int)}")
+    finally:
+        fu.xie_propagation_points_in_order, fu.MIQP = orig_in_order, orig_miqp
+    save("GX2_xie_bfstree", **out)
+
+
 def make_inference_shim():
     """inference_utils.py imports models/ (torch_geometric, absent offline) at module level.
     Only its pure-torch fix_n_filter is on the path; load that one function's source object by
@@ -685,7 +733,7 @@ def make_inference_shim():
     spec.loader.exec_module(mod)
 
 
-ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13, G14=g14, G15=g15, G16=g16, GW=gw)
+ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13, G14=g14, G15=g15, G16=g16, GW=gw, GX2=gx2)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
