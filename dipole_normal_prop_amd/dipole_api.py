@@ -14,9 +14,10 @@ def orient_large(opts):
 def simple_estimate(xyz_data, config):
     """The request handler behind the reference's socket servers (socket_server.py:18-27): numpy xyz in
     (float64 on the wire) -> PCA normals -> unit-box transform -> per-point dipole propagation -> global flip
-    by the mean potential -> numpy [N,6] out in the input's frame and dtype.  The TCP framing itself
-    (JSON header + raw float64, socket_server_para.py:142-195) is outside this package.  The propagation runs
-    in fp32 on the GPU whatever the input dtype (the reference would run it in fp64 for a float64 cloud)."""
+    by the mean potential -> numpy [N,6] out in the input's frame and dtype.  A float64 cloud (what arrives on
+    the wire, util.py:71-77) stays float64 throughout: the per-point propagation runs in the fp64 kernel
+    (dnp_point_greedy_f64), as the reference's does.  The wire framing around this handler (JSON header + raw
+    float64, socket_server_para.py:142-195) is dipole_normal_prop_amd.wire; the TCP server itself is not built."""
     import torch
     from . import field_utils, util
     dev = torch.device("cuda", torch.cuda.current_device())
