@@ -170,11 +170,15 @@ __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restri
             if (s < 0.0) negative |= 1ull << (cur >> 6);
         }
         const double* row = W + (int64_t)cur * P;
+        double r[EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int j = e * 64 + lane;
-            if (j < P) inter[e] += s * row[j];           // s = +-1: the product is exact
+        for (int e = 0; e < EPL; ++e) {                  // unconditional (clamped) loads: all EPL in flight at once -
+            const int j = e * 64 + lane;                 // a predicated load per entry would be EPL serial round trips
+            r[e] = row[j < P ? j : P - 1];
         }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+            if (e * 64 + lane < P) inter[e] += s * r[e]; // s = +-1: the product is exact
         if (step + 1 == P) break;
         // first maximum of |I_j| in patch order; a NaN counts as the maximum, as in torch.argmax
         double bv = -1.0;
