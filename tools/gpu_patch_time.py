@@ -3,11 +3,11 @@
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from dipole_normal_prop_amd import field_utils as fu
+from dipole_normal_prop_amd import field_utils as fu, util
 from bench import sphere_cloud, fibonacci_patches
 dev = torch.device("cuda:0")
 pc = sphere_cloud(); patches = fibonacci_patches(pc)
-off, idx = fu._csr(patches, dev)
+off, idx, _ = util.patch_csr(patches, dev)
 pts = pc.to(dev)[idx].contiguous()
 pp = torch.repeat_interleave(torch.arange(256, device=dev), off[1:] - off[:-1])
 for _ in range(3): fu._patch_slabs(pts, off, None, pp, 0, 256, 1e-5)
