@@ -250,8 +250,7 @@ __global__ __launch_bounds__(256) void store_normals_kernel(F* __restrict__ pts,
 
 
 // ---- multi-workgroup form --------------------------------------------------------------------------------------
-// G workgroups (one per CU, all co-resident: launched with hipLaunchCooperativeKernel, which refuses a grid the
-// device cannot hold at once), each owning a contiguous slice of the cloud in registers.
+// G workgroups (one per CU, all co-resident: the launcher checks the grid against the occupancy query), each owning a contiguous slice of the cloud in registers.
 // Per step every workgroup publishes its local winner as naturally aligned 8-byte granules
 //   fp32:  { float signed_interaction ; uint32 (step & 0xfff) << 20 | point_index }          (index < 2^20)
 //   fp64:  two granules { high / low 32 bits of the signed interaction ; the same tag|index word }
@@ -512,12 +511,20 @@ static int run_point_greedy(F* pts, int64_t N, int64_t ld_pts, int64_t start, F 
         // tags start at step 0: every slot must hold a tag that no early step uses
         DNP_CHECK_HIP(hipMemsetAsync(slots, 0xff, kGreedySlots, st));
         MultiArgs<F> ma{pts, N, ld_pts, (int)start, eps, diffuse, order_out, E_out, n_out, slots, status, (int)per};
-        void* kargs[] = {(void*)&ma};
-        // cooperative launch: the runtime checks the grid against what the device can hold at once, so the
-        // all-gather can never wait for a workgroup that is not resident
-#define DNP_LAUNCH_MULTI(P)                                                                                        \
-    DNP_CHECK_HIP(hipLaunchCooperativeKernel((const void*)(point_greedy_multi_kernel<F, P>), dim3(groups),         \
-                                             dim3(kGreedyThreads), kargs, 0, st))
+        // Co-residency: the all-gather may only wait for workgroups that are on the chip.  One workgroup per CU at
+        // most, and the occupancy query must confirm that a CU holds one (the check hipLaunchCooperativeKernel would
+        // make; the cooperative launch itself is avoided because rocprofv3 (ROCm 7.2) crashes at exit in a process
+        // that used it).  Every spin in the kernel is bounded besides.
+#define DNP_LAUNCH_MULTI(P)                                                                                         \
+    do {                                                                                                            \
+        int per_cu = 0;                                                                                             \
+        DNP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, point_greedy_multi_kernel<F, P>,        \
+                                                                   kGreedyThreads, 0));                             \
+        DNP_REQUIRE(per_cu >= 1 && groups <= cus, "%d workgroups of the per-point kernel cannot be co-resident on " \
+                    "%d CUs (%d per CU)", groups, cus, per_cu);                                                     \
+        hipLaunchKernelGGL((point_greedy_multi_kernel<F, P>), dim3(groups), dim3(kGreedyThreads), 0, st, ma);       \
+        DNP_CHECK_HIP(hipGetLastError());                                                                           \
+    } while (0)
         if (ppt <= 1) DNP_LAUNCH_MULTI(1);
         else if (ppt <= 2) DNP_LAUNCH_MULTI(2);
         else if (ppt <= 4) DNP_LAUNCH_MULTI(4);

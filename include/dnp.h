@@ -155,7 +155,7 @@ int dnp_combine_fields_f32(const float* dE, int64_t K, int64_t N,
  * float64 clouds to this driver (util.py:71-77, socket_server.py:18-27).
  *
  * form: 0 = choose by N, 1 = single workgroup (N <= 512*20 fp32 / 512*8 fp64), 2 = one workgroup per CU
- * (cooperative launch; N < 2^20).  max_groups > 0 caps the workgroup count of form 2.  The first int of the
+ * (co-residency checked against the occupancy query; N < 2^20).  max_groups > 0 caps the workgroup count of form 2.  The first int of the
  * workspace is a status word: non-zero after the launch means a workgroup of form 2 gave up waiting for its
  * peers (GPU shared with another process); pts is then unchanged garbage-free input and the caller should fall
  * back to step-wise launches of dnp_field_grad.

@@ -1,0 +1,16 @@
+import sys, torch
+sys.path.insert(0, "/root/repo")
+from dipole_normal_prop_amd import field_utils as fu
+from tools.gpu_check import sphere
+which = sys.argv[1]
+dev = torch.device("cuda:0")
+if which == "coop":
+    fu.POINT_GREEDY_FORM = 2
+    fu.strongest_field_propagation_points(sphere(3000).to(dev), diffuse=True)
+elif which == "single":
+    fu.POINT_GREEDY_FORM = 1
+    fu.strongest_field_propagation_points(sphere(3000).to(dev), diffuse=True)
+else:
+    fu.field_grad(sphere(3000).to(dev), sphere(3000).to(dev))
+torch.cuda.synchronize()
+print("done", which)
