@@ -161,7 +161,10 @@ __device__ __forceinline__ void pair_field(F sx, F sy, F sz, F px, F py, F pz, F
 // truncated after e^2: relative error e^3 < kFarRatio^3 = 8e-9, an eighth of an fp32 ulp.  22 full-rate + 1
 // quarter-rate instructions against 19 + 2 for the exact chain (a transcendental costs ~13 issue cycles when
 // mixed with FMAs).  No coincident pair can be in a far tile.
-constexpr double kFarRatio = 2e-3;
+#ifndef DNP_FAR_RATIO
+#define DNP_FAR_RATIO 2e-3
+#endif
+constexpr double kFarRatio = DNP_FAR_RATIO;
 
 template <typename F>
 __device__ __forceinline__ void pair_field_far(F sx, F sy, F sz, F px, F py, F pz, F tx, F ty, F tz, F eps,
