@@ -123,8 +123,8 @@ def other_configs(dev, fu, util, pts_sorted, patch_ranges):
         cloud[~torch.from_numpy(g15["prefilter_sign"]), 3:] *= -1
         cloud = cloud.to(dev)
         i64 = lambda a: torch.from_numpy(a.astype(np.int64)).to(dev)
-        reps = [(i64(g15["rep_idx"][g15["rep_off"][k]:g15["rep_off"][k + 1]]),
-                 i64(g15["rest_idx"][g15["rest_off"][k]:g15["rest_off"][k + 1]])) for k in range(len(g15["rep_off"]) - 1)]
+        reps = util.RepLists(util.PatchList(i64(g15["rep_idx"]), np.diff(g15["rep_off"]), disjoint=True),
+                             util.PatchList(i64(g15["rest_idx"]), np.diff(g15["rest_off"]), disjoint=True))
         t = timed(lambda: fu.strongest_field_propagation_reps(cloud.clone(), reps, diffuse=True), 3)
         nrep = int(g15["rep_off"][-1])
         out["config3_boxunion_reps_propagation"] = {

@@ -155,18 +155,24 @@ class _WarnState:
         self.dev_base, self.host_base = self.ring.data_ptr(), self.host.data_ptr()
         self.head = 0             # next slot to hand out
         self.tail = 0             # oldest slot not yet reported
+        self.lock = threading.Lock()   # flush_warnings() may drain this state from another thread
         torch.cuda.current_stream(dev).synchronize()                  # the ring is initialised before its first use
 
     def next_slot(self):
         if self.head - self.tail >= _WARN_RING:                       # every slot is in flight: wait for the oldest
             self.drain(block=True)
-        i = self.head % _WARN_RING
-        self.head += 1
+        with self.lock:
+            i = self.head % _WARN_RING
+            self.head += 1
         return (ctypes.c_void_p(self.dev_base + 12 * i), ctypes.c_void_p(self.host_base + 12 * i))
 
     def drain(self, block=False):
         if block and self.tail < self.head:
             torch.cuda.synchronize(self.dev)
+        with self.lock:
+            self._drain_landed()
+
+    def _drain_landed(self):
         while self.tail < self.head:
             i = self.tail % _WARN_RING
             if self.view[i, 2] != 1:
@@ -787,14 +793,19 @@ def strongest_field_propagation_reps(input_pc, reps, diffuse=False, weights=None
         work, w = _prepare_work(input_pc, weights)
         dev = work.device
         N = work.shape[0]
-        rep_csr = util.patch_csr([r for r, _ in reps], dev)
-        rest_csr = util.patch_csr([r for _, r in reps], dev)
+        known_disjoint = False
+        if isinstance(reps, util.RepLists):
+            rep_csr, rest_csr = util.patch_csr(reps.reps, dev), util.patch_csr(reps.rests, dev)
+            known_disjoint = reps.reps.disjoint
+        else:
+            rep_csr = util.patch_csr([r for r, _ in reps], dev)
+            rest_csr = util.patch_csr([r for _, r in reps], dev)
         _, all_reps, rep_sizes = rep_csr
         rep_lists = util.PatchList(all_reps, rep_sizes)
         start_t = _start_tensor(work, rep_lists, start_patch)
         mode = PATCH_MODE
         if mode == "auto":
-            mode = "batched" if _disjoint(all_reps, N) else "sequential"
+            mode = "batched" if known_disjoint or _disjoint(all_reps, N) else "sequential"
         # the loop's targets are representatives only: run it on the compact sub-cloud of the representatives
         # (patch k = the contiguous row range of its representatives) and scatter back
         sub = work[all_reps].contiguous()
@@ -821,9 +832,11 @@ def strongest_field_propagation_reps(input_pc, reps, diffuse=False, weights=None
         if int(rep_sizes.sum()) < N or mode != "batched":
             rest = torch.nonzero(~is_rep).flatten()
             if rest.numel():
-                src_idx = torch.nonzero(is_rep).flatten()
+                # field_grad(pts[oriented_pts_mask], pts[~oriented_pts_mask]): sources in point order, as a compact
+                # copy (contiguous rows go through the scalar-unit kernel; a row gather would need the LDS one)
+                src = work[is_rep].contiguous()
                 E2 = torch.empty((rest.shape[0], 3), dtype=torch.float32, device=dev)
-                _pairs_into("field", work, src_idx, work, rest, 1e-5, 15000, E2)
+                _pairs_into("field", src, None, work, rest, 1e-5, 15000, E2)
                 s = ((E2 * work[rest, 3:]).sum(dim=-1) > 0).float() * 2 - 1
                 work[rest, 3:] = work[rest, 3:] * s[:, None]
         _finish_patch_driver(input_pc, work, w)

@@ -112,6 +112,27 @@ def orient_patches(opts):
     return cloud
 
 
+def _representatives(every):
+    """<= REPRESENTATIVES_PER_PATCH random points per patch and the rest (orient_large.py:48-52): one
+    torch.randperm per patch on the CPU generator, in patch order - the reference's random stream under
+    torch.manual_seed(1) - assembled into two index vectors on the host and gathered on the device ONCE."""
+    if not isinstance(every, util.PatchList):
+        every = util.PatchList(torch.cat(list(every)), [int(p.shape[0]) for p in every])
+    rep_pos, rest_pos, rep_sizes, rest_sizes, start = [], [], [], [], 0
+    for n in every.sizes:
+        shuffle = torch.randperm(n)
+        rep_pos.append(shuffle[:REPRESENTATIVES_PER_PATCH] + start)
+        rest_pos.append(shuffle[REPRESENTATIVES_PER_PATCH:] + start)
+        rep_sizes.append(min(n, REPRESENTATIVES_PER_PATCH))
+        rest_sizes.append(max(n - REPRESENTATIVES_PER_PATCH, 0))
+        start += n
+    flat = every.flat
+    rep_flat = flat[torch.cat(rep_pos).to(flat.device)] if rep_pos else flat[:0]
+    rest_flat = flat[torch.cat(rest_pos).to(flat.device)] if rest_pos else flat[:0]
+    return util.RepLists(util.PatchList(rep_flat, rep_sizes, disjoint=every.disjoint),
+                         util.PatchList(rest_flat, rest_sizes, disjoint=every.disjoint))
+
+
 def orient_representatives(opts):
     options.reject_models(opts)
     stages = _Stages()
@@ -122,10 +143,7 @@ def orient_representatives(opts):
         raise SystemExit("the cloud has no normals: pass --estimate_normals")
     kept, every = _partition(cloud, opts, stages)
     with stages("find reps"):
-        reps = []
-        for rows in every:
-            shuffle = torch.randperm(rows.shape[0]).to(rows.device)
-            reps.append((rows[shuffle[:REPRESENTATIVES_PER_PATCH]], rows[shuffle[REPRESENTATIVES_PER_PATCH:]]))
+        reps = _representatives(every)
     with stages("propagating field"):
         field_utils.strongest_field_propagation_reps(cloud, reps, diffuse=True)
     _global_flip(cloud, stages)

@@ -164,6 +164,16 @@ class PatchList(list):
         super().__init__(torch.split(flat, self.sizes) if len(self.sizes) else [])
 
 
+class RepLists(list):
+    """The `reps` argument of strongest_field_propagation_reps - a list of (representatives, rest) index pairs, one
+    per patch (orient_large.py:48-52) - that remembers both sides as PatchLists, so the driver needs no
+    concatenation of hundreds of small tensors."""
+
+    def __init__(self, reps: PatchList, rests: PatchList):
+        self.reps, self.rests = reps, rests
+        super().__init__(zip(reps, rests))
+
+
 def patch_csr(patches, dev):
     """(off[P+1] int64 on dev, idx[M] int64 on dev, sizes[P] numpy int64) of a list of index tensors."""
     if isinstance(patches, PatchList) and len(patches) == len(patches.sizes):

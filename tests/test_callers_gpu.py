@@ -127,12 +127,36 @@ def test_config3_boxunion_reps_propagation_matches_the_reference(dev):
     assert (phi < 0) == (float(g["mean_potential"]) < 0) and abs(phi / float(g["mean_potential"]) - 1) < 1e-3
 
 
+def test_headline_size_patch_propagation_on_boxunion(dev):
+    """BASELINE config 4's driver at its size on a reference-held cloud: strongest_field_propagation, diffuse, on
+    boxunion (100 000 points, the reference's 369 patches and kept list) = 10^10 pair evaluations in the reference
+    (G17: ~8 minutes on the build container).  Complete visit order, flips, chosen interactions and all 100 000
+    signs; start pinned for the reason given above (exactly planar patches)."""
+    g, pc, cloud, _ = _config3_case(dev)
+    g17 = load_golden("G17_boxunion_patch_propagation")
+    i64 = lambda a: torch.from_numpy(a.astype(np.int64))
+    allp = util.PatchList(i64(g["patch_idx"]).to(dev), np.diff(g["patch_off"]), disjoint=True)
+    patches = [(int(i), allp[int(i)]) for i in g["kept"]]
+    pts = cloud.clone().to(dev)
+    fu.strongest_field_propagation(pts, patches, allp, diffuse=True, start_patch=int(g17["order"][0]))
+    tr = fu.last_trace("patches")
+    first_diff = int(np.argmax(tr["order"] != g17["order"])) if (tr["order"] != g17["order"]).any() else -1
+    assert first_diff == -1, f"visit order leaves the reference at step {first_diff}"
+    assert np.array_equal((tr["sigma"] < 0)[tr["order"]], g17["flipped"])
+    assert np.allclose(tr["chosen"], g17["chosen"], rtol=2e-4)
+    sign = ((pts.cpu()[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy()
+    assert np.array_equal(sign, g17["sign"])
+
+
 def test_config3_boxunion_default_start_reaches_the_same_orientation(dev):
     """Without the pin the driver starts from the first exactly-flat patch (another member of the reference's tie
     class), visits the patches in a different order - and must still end, after the global potential fix, with the
     orientation the reference ends with (up to the diffuse pass's coin flips on points whose E.n is rounding noise:
     fewer than 1 in 10 000)."""
     g, pc, cloud, reps = _config3_case(dev)
+    i64 = lambda a: torch.from_numpy(a.astype(np.int64)).to(dev)
+    reps = util.RepLists(util.PatchList(i64(g["rep_idx"]), np.diff(g["rep_off"]), disjoint=True),   # the callers' form
+                         util.PatchList(i64(g["rest_idx"]), np.diff(g["rest_off"]), disjoint=True))
     pts = cloud.clone().to(dev)
     fu.strongest_field_propagation_reps(pts, reps, diffuse=True)
     tr = fu.last_trace("reps")

@@ -718,6 +718,29 @@ def gx2(fu, util):
     save("GX2_xie_bfstree", **out)
 
 
+def g17(fu, util):
+    """The patch driver at the headline size on a reference-held cloud: strongest_field_propagation
+    (field_utils.py:286-348) on the G15 boxunion cloud (100 000 points, the reference's 369 patches, its
+    fix_n_filter / orient_center state and kept list), diffuse, no weights - 10^10 pair evaluations in the
+    reference.  Inputs are G15's; only the trace and the signs are stored here."""
+    g = np.load(os.path.join(OUT, "G15_boxunion_config3.npz"))
+    pc = torch.from_numpy(g["pc"]).clone()
+    pc[~torch.from_numpy(g["prefilter_sign"]), 3:] *= -1
+    off, idx = g["patch_off"], torch.from_numpy(g["patch_idx"].astype(np.int64))
+    allp = [idx[off[k]:off[k + 1]].clone() for k in range(len(off) - 1)]
+    patches = [(int(i), allp[int(i)]) for i in g["kept"]]
+    t0 = time.time()
+    pts, calls, inter = _run_patch_driver(fu, util, "patch", pc, patches, allp, True, None)
+    print(f"  reference patch propagation at 100k: {time.time() - t0:.1f}s")
+    firsts = [(int(p[0]), pc[int(p[0]), :3]) for p in allp]
+    mins = [(int(p.min()), pc[int(p.min()), :3]) for p in allp]
+    order, flipped = _order_from_calls(calls, pc, firsts, mins)
+    save("G17_boxunion_patch_propagation", order=order, flipped=flipped,
+         chosen=np.array([float(t[t.abs().argmax()]) for t in inter]),
+         sign=((pts[:, 3:] * pc[:, 3:]).sum(-1) > 0),
+         curv=np.array([util.pca_eigen_values(pc[p])[0].item() for p in allp]))
+
+
 def make_inference_shim():
     """inference_utils.py imports models/ (torch_geometric, absent offline) at module level.
     Only its pure-torch fix_n_filter is on the path; load that one function's source object by
@@ -733,7 +756,7 @@ def make_inference_shim():
     spec.loader.exec_module(mod)
 
 
-ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13, G14=g14, G15=g15, G16=g16, GW=gw, GX2=gx2)
+ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13, G14=g14, G15=g15, G16=g16, GW=gw, GX2=gx2, G17=g17)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
