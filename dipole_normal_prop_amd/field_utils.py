@@ -827,18 +827,27 @@ def strongest_field_propagation_reps(input_pc, reps, diffuse=False, weights=None
         if diffuse:
             _diffuse_sign_pass(work, E, rep_lists)
         # every non-representative point: sign of the field of all representatives
-        is_rep = torch.zeros(N, dtype=torch.bool, device=dev)
-        is_rep[all_reps] = True
-        if int(rep_sizes.sum()) < N or mode != "batched":
+        # (field_grad(pts[oriented_pts_mask], pts[~oriented_pts_mask]): both sides in point order)
+        n_rest = int(rest_csr[2].sum())
+        if known_disjoint and int(rep_sizes.sum()) + n_rest == N and isinstance(reps, util.RepLists) \
+                and reps.rests.disjoint:
+            # representatives and rests partition the cloud (what the callers pass): no mask, no host round trip
+            rest = torch.sort(rest_csr[1]).values if n_rest else None
+            src_rows = torch.sort(all_reps).values
+        else:
+            is_rep = torch.zeros(N, dtype=torch.bool, device=dev)
+            is_rep[all_reps] = True
             rest = torch.nonzero(~is_rep).flatten()
-            if rest.numel():
-                # field_grad(pts[oriented_pts_mask], pts[~oriented_pts_mask]): sources in point order, as a compact
-                # copy (contiguous rows go through the scalar-unit kernel; a row gather would need the LDS one)
-                src = work[is_rep].contiguous()
-                E2 = torch.empty((rest.shape[0], 3), dtype=torch.float32, device=dev)
-                _pairs_into("field", src, None, work, rest, 1e-5, 15000, E2)
-                s = ((E2 * work[rest, 3:]).sum(dim=-1) > 0).float() * 2 - 1
-                work[rest, 3:] = work[rest, 3:] * s[:, None]
+            rest = rest if rest.numel() else None
+            src_rows = torch.nonzero(is_rep).flatten()
+        if rest is not None:
+            # sources as a compact copy: contiguous rows go through the scalar-unit kernel, a row gather would
+            # need the LDS one
+            src = work[src_rows].contiguous()
+            E2 = torch.empty((rest.shape[0], 3), dtype=torch.float32, device=dev)
+            _pairs_into("field", src, None, work, rest, 1e-5, 15000, E2)
+            s = ((E2 * work[rest, 3:]).sum(dim=-1) > 0).float() * 2 - 1
+            work[rest, 3:] = work[rest, 3:] * s[:, None]
         _finish_patch_driver(input_pc, work, w)
         _set_trace("reps", order=order, sigma=sigma, chosen=chosen, start=start_t)
 

@@ -167,7 +167,9 @@ class PatchList(list):
 class RepLists(list):
     """The `reps` argument of strongest_field_propagation_reps - a list of (representatives, rest) index pairs, one
     per patch (orient_large.py:48-52) - that remembers both sides as PatchLists, so the driver needs no
-    concatenation of hundreds of small tensors."""
+    concatenation of hundreds of small tensors.  When both PatchLists are flagged disjoint and their sizes add up to
+    the cloud, the driver takes representatives and rests as a partition of the cloud (what splitting a partition's
+    patches gives) and needs no mask round trip to find the non-representative points."""
 
     def __init__(self, reps: PatchList, rests: PatchList):
         self.reps, self.rests = reps, rests
