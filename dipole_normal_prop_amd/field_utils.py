@@ -397,14 +397,20 @@ def _point_patch_ids(idx: torch.Tensor, sizes: np.ndarray, n: int) -> torch.Tens
     return point_patch
 
 
-def _flip_by_listing(work: torch.Tensor, neg: torch.Tensor, lists_csr) -> None:
-    """work[idx, 3:] *= -1 once per listing of a point in a patch k with neg[k] (the reference's loop flips a
-    point every time it is listed): parity of the listing count, all on the device."""
+def _listing_ids(lists_csr) -> torch.Tensor:
+    """patch id of every entry of a CSR index list (device)."""
     off, idx, sizes = lists_csr
+    return torch.repeat_interleave(torch.arange(len(sizes), device=idx.device), util.to_device(sizes, idx.device),
+                                   output_size=int(idx.numel()))
+
+
+def _flip_by_listing(work: torch.Tensor, neg: torch.Tensor, idx: torch.Tensor, pid: torch.Tensor) -> None:
+    """work[idx, 3:] *= -1 once per listing of a point in a patch k with neg[k] (the reference's loop flips a
+    point every time it is listed): parity of the listing count, all on the device.  pid = _listing_ids(...),
+    built BEFORE the long kernels are enqueued: a host->device copy behind them would stall the host until
+    they have finished."""
     if idx.numel() == 0:
         return
-    pid = torch.repeat_interleave(torch.arange(len(sizes), device=idx.device), torch.from_numpy(sizes).to(idx.device),
-                                  output_size=int(idx.numel()))
     cnt = torch.zeros(work.shape[0], dtype=torch.int32, device=work.device)
     cnt.index_add_(0, idx, neg[pid].to(torch.int32))
     s = (1 - 2 * (cnt % 2)).to(work.dtype)
@@ -578,7 +584,7 @@ def _listed_patches(patches, all_patches, dev) -> Optional[torch.Tensor]:
     flags = np.zeros(len(all_patches), dtype=np.uint8)
     if len(patches):
         flags[[i for i, _ in patches]] = 1
-    return torch.from_numpy(flags).to(dev)
+    return util.to_device(flags, dev)
 
 
 def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tensor, diffuse: bool,
@@ -599,7 +605,7 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
     # data layout for the kernels: the cloud sorted by patch (points in no patch last), so that a patch
     # is a contiguous row range - sources stream linearly and K3 reads its slab rows coalesced
     covered = int(sizes.sum())
-    point_patch = torch.repeat_interleave(torch.arange(P, device=dev), torch.from_numpy(sizes).to(dev),
+    point_patch = torch.repeat_interleave(torch.arange(P, device=dev), util.to_device(sizes, dev),
                                           output_size=covered)
     if covered == N:
         perm = idx
@@ -763,8 +769,8 @@ def strongest_field_propagation(pts, patches, all_patches, diffuse=False, weight
             known = isinstance(all_patches, util.PatchList) and all_patches.disjoint
             mode = "batched" if known or _disjoint(_csr(all_patches, dev)[1], work.shape[0]) else "sequential"
         if mode == "batched":
+            listed = _listed_patches(patches, all_patches, dev) if diffuse else None   # host->device copy: before the long kernels
             st = _batched_patch_propagation(work, all_patches, start_t, diffuse)
-            listed = _listed_patches(patches, all_patches, dev) if diffuse else None
             if not diffuse or listed is not None:
                 _finish_batched(pts, st, diffuse, listed, w)
             else:                                       # diffuse lists that are not the patches themselves
@@ -801,7 +807,8 @@ def strongest_field_propagation_reps(input_pc, reps, diffuse=False, weights=None
             rep_csr = util.patch_csr([r for r, _ in reps], dev)
             rest_csr = util.patch_csr([r for _, r in reps], dev)
         _, all_reps, rep_sizes = rep_csr
-        rep_lists = util.PatchList(all_reps, rep_sizes)
+        rep_pid, rest_pid = _listing_ids(rep_csr), _listing_ids(rest_csr)      # every host->device copy happens here,
+        rep_lists = util.PatchList(all_reps, rep_sizes)                        # before the long kernels are enqueued
         start_t = _start_tensor(work, rep_lists, start_patch)
         mode = PATCH_MODE
         if mode == "auto":
@@ -822,8 +829,8 @@ def strongest_field_propagation_reps(input_pc, reps, diffuse=False, weights=None
                                                                         diffuse)
             E[all_reps] = E_sub
             neg = torch.from_numpy(sigma < 0).to(dev)
-        _flip_by_listing(work, neg, rep_csr)
-        _flip_by_listing(work, neg, rest_csr)
+        _flip_by_listing(work, neg, all_reps, rep_pid)
+        _flip_by_listing(work, neg, rest_csr[1], rest_pid)
         if diffuse:
             _diffuse_sign_pass(work, E, rep_lists)
         # every non-representative point: sign of the field of all representatives

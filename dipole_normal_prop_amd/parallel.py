@@ -103,10 +103,10 @@ def sharded_patch_propagation(pts: torch.Tensor, patches, all_patches, diffuse=F
             return
         work, w = fu._prepare_work(pts, weights)
         start_t = agree_on_start(fu._start_tensor(work, all_patches, start_patch))
+        listed = fu._listed_patches(patches, all_patches, work.device) if diffuse else None
         st = fu._batched_patch_propagation(work, all_patches, start_t, diffuse, shard=(rank, size, gather_rows))
         if diffuse and st.Es is not None:
             st.Es = reduce_field(st.Es)                 # patch-sorted rows: the same permutation on every rank
-        listed = fu._listed_patches(patches, all_patches, work.device) if diffuse else None
         if not diffuse or listed is not None:
             fu._finish_batched(pts, st, diffuse, listed, w)
         else:

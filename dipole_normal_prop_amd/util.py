@@ -164,6 +164,15 @@ class PatchList(list):
         super().__init__(torch.split(flat, self.sizes) if len(self.sizes) else [])
 
 
+def to_device(arr: np.ndarray, dev) -> torch.Tensor:
+    """Small host array -> device tensor without stalling the host: through pinned memory with a non-blocking
+    copy (a copy from pageable memory makes the host wait for everything already enqueued on the stream)."""
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    if torch.device(dev).type != "cuda":
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
 class RepLists(list):
     """The `reps` argument of strongest_field_propagation_reps - a list of (representatives, rest) index pairs, one
     per patch (orient_large.py:48-52) - that remembers both sides as PatchLists, so the driver needs no
@@ -185,7 +194,7 @@ def patch_csr(patches, dev):
         sizes = np.array([int(p.shape[0]) for p in patches], dtype=np.int64)
         idx = torch.cat([p.to(device=dev, dtype=torch.int64) for p in patches]) if len(patches) else \
             torch.zeros(0, dtype=torch.int64, device=dev)
-    off = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)).to(dev)
+    off = to_device(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64), dev)
     return off, idx, sizes
 
 
