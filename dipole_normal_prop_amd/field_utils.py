@@ -393,7 +393,7 @@ def _point_patch_ids(idx: torch.Tensor, sizes: np.ndarray, n: int) -> torch.Tens
     point_patch = torch.full((n,), -1, dtype=torch.int64, device=dev)
     if idx.numel():
         point_patch[idx] = torch.repeat_interleave(torch.arange(len(sizes), device=dev),
-                                                   torch.from_numpy(sizes).to(dev), output_size=int(idx.numel()))
+                                                   util.to_device(sizes, dev), output_size=int(idx.numel()))
     return point_patch
 
 

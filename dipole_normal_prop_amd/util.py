@@ -369,7 +369,7 @@ def fix_n_filter(input_pc: torch.Tensor, patch_indices: List[torch.Tensor], thre
     if not keep_host.all():
         P = len(sizes)
         pid = torch.repeat_interleave(torch.arange(P, device=input_pc.device),
-                                      torch.from_numpy(sizes).to(input_pc.device), output_size=int(sizes.sum()))
+                                      to_device(sizes, input_pc.device), output_size=int(sizes.sum()))
         sel = ~keep[pid]
         rows, normal = idx[sel], v[:, :, 0].to(input_pc.dtype)[pid[sel]]
         s = ((input_pc[rows, 3:] * normal).sum(dim=-1) > 0).to(input_pc.dtype) * 2 - 1
@@ -388,7 +388,7 @@ def orient_center_patches(input_pc: torch.Tensor, patches: List[torch.Tensor]) -
             input_pc[p] = orient_center(input_pc[p])
         return
     pid = torch.repeat_interleave(torch.arange(len(sizes), device=input_pc.device),
-                                  torch.from_numpy(sizes).to(input_pc.device), output_size=int(sizes.sum()))
+                                  to_device(sizes, input_pc.device), output_size=int(sizes.sum()))
     rel = input_pc[idx, :3] - mean.to(input_pc.dtype)[pid]
     inward = (rel * input_pc[idx, 3:]).sum(dim=-1) < 0
     rows = idx[inward]
