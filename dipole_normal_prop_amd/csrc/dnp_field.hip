@@ -16,17 +16,19 @@
 
 namespace dnp {
 
-// shortest chunk a leaf is cut into: 64 sources, growing to 512 for very large source sets (S / 512),
-// so that the by-value chunk table (512 entries) always suffices for one round per ~262 000 sources
 #ifndef DNP_MINCHUNK_CAP
 #define DNP_MINCHUNK_CAP 512
 #endif
+// shortest chunk a leaf is cut into.  Scalar kernel: 64 sources, growing to 512 for very large source sets (S / 512)
+// so that the by-value chunk table (512 entries) suffices for one round per ~262 000 sources.  LDS kernel: S / 64
+// clamped to [64, 512] - it stages 256-row tiles, and a chunk of less than two tiles has no load/compute overlap.
 #ifndef DNP_MINCHUNK_DIV
 #define DNP_MINCHUNK_DIV 512
 #endif
-static inline int64_t min_chunk(int64_t S) { const int64_t m = S / DNP_MINCHUNK_DIV; return m < 64 ? 64 : (m > DNP_MINCHUNK_CAP ? DNP_MINCHUNK_CAP : m); }
-// targets per lane for large target sets: 2 in the scalar-unit kernel (contiguous sources), 4 in the LDS kernel
-// (gathered sources; swept: 4 x 2 accumulator sets); 1 for small target sets in both
+static inline int64_t min_chunk(int64_t S, bool scalar_kernel) {
+    const int64_t m = S / (scalar_kernel ? DNP_MINCHUNK_DIV : 64);
+    return m < 64 ? 64 : (m > DNP_MINCHUNK_CAP ? DNP_MINCHUNK_CAP : m);
+}
 constexpr int kKTScalar = 2, kKTLds = 4;
 constexpr int64_t kTilesForLarge = 16;     // ... used once that still leaves >= 16 target tiles (T >= 8192 / 16384)
 constexpr size_t kSlabCap = (size_t)1 << 30;  // bytes of partial slab per round
@@ -64,7 +66,11 @@ static void split_leaves(int64_t lo, int64_t hi, int64_t max_pts, std::vector<in
 // make_plan clips the answer by the shortest chunk it allows and by the by-value chunk table.
 constexpr int64_t kChunkSources = 256, kWantBlocks = 4096, kShortestUseful = 128;
 constexpr size_t kSlabTarget = (size_t)320 << 20;
-static int64_t choose_chunks(int64_t S, int64_t T, int64_t t_tiles, int64_t n_leaves, int nc) {
+static int64_t choose_chunks(int64_t S, int64_t T, int64_t t_tiles, int64_t n_leaves, int nc, bool scalar_kernel) {
+    if (!scalar_kernel) {        // LDS kernel (small problems, gathered sources): ~8192 workgroups, the round-1 rule
+        const int64_t want = ceil_div((int64_t)8192, t_tiles);
+        return want < n_leaves ? n_leaves : want;
+    }
     int64_t want = S / kChunkSources;
     int64_t fill = ceil_div(kWantBlocks, t_tiles);          // small target sets: more workgroups, but not chunks so
     if (fill > S / kShortestUseful) fill = S / kShortestUseful;   // short that the workgroup prologue dominates
@@ -92,7 +98,7 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
     int64_t cap = (int64_t)(kSlabCap / ((size_t)(T > 0 ? T : 1) * nc * elem));
     if (cap > kMaxChunks) cap = kMaxChunks;
     if (cap < 1) cap = 1;
-    int64_t want = choose_chunks(S, T, t_tiles, n_leaves, nc);
+    int64_t want = choose_chunks(S, T, t_tiles, n_leaves, nc, scalar_kernel);
 #ifdef DNP_FORCE_CHUNKS   // planning experiments only
     want = DNP_FORCE_CHUNKS;
 #endif
@@ -129,7 +135,7 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
         const int64_t hi = cuts[l];
         const int64_t len = hi - lo;
         int64_t m = per_leaf[(size_t)l];
-        const int64_t m_max = len / min_chunk(S) > 0 ? len / min_chunk(S) : 1;
+        const int64_t m_max = len / min_chunk(S, scalar_kernel) > 0 ? len / min_chunk(S, scalar_kernel) : 1;
         if (m > m_max) m = m_max;
         if (m > cap) m = cap;
         if (m < 1) m = 1;
