@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel-trace stats of the whole GPU test suite: which native kernels ran, how often, how long.
-set -e
+set +e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_suite
