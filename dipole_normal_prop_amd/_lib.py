@@ -51,6 +51,9 @@ SIGNATURES = {
     "dnp_combine_signed_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, ctypes.c_int, _c_p]),
     "dnp_patch_finish_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64,
                                             ctypes.c_int, _c_p]),
+    "dnp_xyz_format_bound": (_c_i64, [_c_i64, _c_i64]),
+    "dnp_xyz_format_f32": (_c_i64, [_c_p, _c_i64, _c_i64, _c_p, _c_i64]),
+    "dnp_xyz_parse_f32": (_c_i64, [_c_p, _c_i64, _c_p, _c_i64, _c_p]),
     "dnp_merge_cells": (ctypes.c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p]),
 }
 

@@ -12,6 +12,7 @@ Reference behaviour each function reproduces (file:line under the reference tree
     pca_eigen_values    util.py:495-500    smallest covariance eigen-pair of a patch
     timer_factory       util.py:612-649    wall-clock stage timer
 """
+import ctypes
 import time
 from typing import List, Tuple
 
@@ -40,11 +41,49 @@ def orient_center(pred: torch.Tensor) -> torch.Tensor:
 
 def export_pc(pc: torch.Tensor, dest) -> None:
     """Write a [C,N] tensor (the callers pass pc.transpose(0,1)) as N lines of C numbers.
-    Format as the reference: str(float) joined by ' ', lines joined by '\\n', no trailing newline."""
-    rows = pc.transpose(0, 1).detach().cpu().tolist()
-    text = "\n".join(" ".join(str(v) for v in row) for row in rows)
-    with open(dest, "w+") as fh:
+    Format as the reference: str(float) joined by ' ', lines joined by '\n', no trailing newline.  float32
+    clouds are formatted by the native library (dnp_xyz_format_f32: the same bytes, ~10x faster than 600 000
+    str() calls); anything else takes the literal Python path."""
+    rows = pc.transpose(0, 1).detach().cpu()
+    text = _format_rows_native(rows) if rows.dtype == torch.float32 and rows.dim() == 2 else None
+    if text is None:
+        text = "\n".join(" ".join(str(v) for v in row) for row in rows.tolist()).encode()
+    with open(dest, "wb") as fh:
         fh.write(text)
+
+
+def _format_rows_native(rows: torch.Tensor):
+    try:
+        from . import _lib
+        lib = _lib.load()
+    except Exception:
+        return None
+    arr = np.ascontiguousarray(rows.numpy())
+    cap = int(lib.dnp_xyz_format_bound(arr.shape[0], arr.shape[1]))
+    buf = ctypes.create_string_buffer(cap)
+    n = lib.dnp_xyz_format_f32(arr.ctypes.data, arr.shape[0], arr.shape[1], buf, cap)
+    return buf.raw[:n] if n >= 0 else None
+
+
+def _xyz_native(txt: str, append_normals: bool):
+    """Regular text through the native parser (dnp_xyz_parse_f32); None when the text is not regular or the library
+    is not available - the callers then fall back to the paths below."""
+    try:
+        from . import _lib
+        lib = _lib.load()
+    except Exception:
+        return None
+    raw = txt.encode()
+    max_rows = raw.count(b"\n") + 1
+    out = np.empty((max_rows, 6), dtype=np.float32)
+    ncol = ctypes.c_int32(0)
+    n = lib.dnp_xyz_parse_f32(raw, len(raw), out.ctypes.data, max_rows, ctypes.byref(ncol))
+    if n <= 0 or ncol.value not in (3, 6):
+        return None
+    arr = out.reshape(-1)[: n * ncol.value].reshape(n, ncol.value)
+    if ncol.value == 3 and append_normals:
+        arr = np.concatenate([arr, np.zeros((n, 3), dtype=np.float32)], axis=1)
+    return torch.from_numpy(np.ascontiguousarray(arr))
 
 
 def _xyz_fast(txt: str, append_normals: bool):
@@ -75,7 +114,9 @@ def _xyz_fast(txt: str, append_normals: bool):
 def xyz2tensor(txt: str, append_normals: bool = True) -> torch.Tensor:
     """Parse '.xyz' text: space separated, 3 or 6 columns per line; lines containing 'nan' are
     dropped; 3-column lines get zero normals appended when append_normals."""
-    fast = _xyz_fast(txt, append_normals)
+    fast = _xyz_native(txt, append_normals)
+    if fast is None:
+        fast = _xyz_fast(txt, append_normals)
     if fast is not None:
         return fast
     rows = []

@@ -254,6 +254,22 @@ int dnp_xie_pairs_f64(const double* src, int64_t S, int64_t ld_src, const double
 int dnp_xie_order_f32(const float* M, int64_t N, const int64_t* order, int64_t R, float* weights, float* inter,
                       void* stream);
 
+/* ---- '.xyz' text  (util.export_pc util.py:46-51, util.xyz2tensor util.py:53-69) - HOST functions, host pointers ---
+ *
+ * dnp_xyz_format_f32: rows[n_rows, n_cols] (contiguous floats) -> n_rows lines of n_cols numbers, each written as
+ * Python's str(float(v)) (shortest round-trip digits of the float32 taken as a double; fixed notation for
+ * 1e-4 <= |v| < 1e16, "1e-05" style otherwise), joined by ' ' and '\n', no trailing newline - byte for byte what
+ * the reference writes.  out must hold dnp_xyz_format_bound(n_rows, n_cols) bytes; returns the byte count.
+ *
+ * dnp_xyz_parse_f32: text whose non-blank lines all hold the same number (3 or 6) of single-space separated
+ * numbers -> out[rows, *ncol] (each token parsed as a double and rounded to float, as float(c) + torch.tensor(...,
+ * float32) do).  Returns the row count, or -2 when the text is not of that regular form (a "nan" token, double
+ * spaces, ragged lines, ...: the caller then takes the line-by-line path that defines the semantics).
+ */
+int64_t dnp_xyz_format_bound(int64_t n_rows, int64_t n_cols);
+int64_t dnp_xyz_format_f32(const float* rows, int64_t n_rows, int64_t n_cols, char* out, int64_t cap);
+int64_t dnp_xyz_parse_f32(const char* txt, int64_t len, float* out, int64_t max_rows, int32_t* ncol);
+
 #ifdef __cplusplus
 }
 #endif

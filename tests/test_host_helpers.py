@@ -190,3 +190,30 @@ def test_knn_graph_bfs_routes_and_vote_match_the_reference():
     a[1] = True
     a[2, :3] = True
     assert fu.align_votes(a).tolist() == [False, True, False]
+
+
+def test_native_xyz_text_is_python_str_float_byte_for_byte(tmp_path):
+    """dnp_xyz_format_f32 / dnp_xyz_parse_f32 against the literal Python of util.export_pc / util.xyz2tensor
+    (util.py:46-69): random float32 bit patterns, the notation switch at 1e-4 / 1e16, denormals, signed zero, inf."""
+    rng = np.random.default_rng(7)
+    edge = np.array([0.0, -0.0, 1.0, -1.0, 100.0, 1e-4, 9.9999e-5, 1e-5, 1e16, 9.999e15, 1e22, 123456.0, 0.5,
+                     1e-45, 3.4e38, np.inf, -np.inf, 16777216.0, 0.1, 1e15, 1.5e16, 2.5e-7, 7.0e20, 65504.0],
+                    dtype=np.float32)
+    bits = rng.integers(0, 2 ** 32, 60000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    vals = np.concatenate([edge, bits[~np.isnan(bits)], rng.standard_normal(30000).astype(np.float32)])
+    vals = vals[: len(vals) // 6 * 6].reshape(-1, 6)
+    pc = torch.from_numpy(vals)
+    util.export_pc(pc.transpose(0, 1), tmp_path / "a.xyz")
+    want = "\n".join(" ".join(str(v) for v in row) for row in vals.tolist())
+    assert open(tmp_path / "a.xyz").read() == want
+    back = util.xyz2tensor(want)
+    assert np.array_equal(back.numpy().view(np.uint32), vals.view(np.uint32))      # bit-exact round trip
+    assert util._xyz_native(want, True) is not None                                  # ... through the native parser
+    three = util.xyz2tensor("\n".join(" ".join(str(v) for v in row[:3]) for row in vals[:50].tolist()))
+    assert three.shape == (50, 6) and float(three[:, 3:].abs().max()) == 0
+    # texts that are not regular take the line-by-line path and give the reference's answer
+    irregular = "1 2 3\n4 5 6 0 0 1\nnan 1 2\n\n7.5 8 9e-1"
+    assert util._xyz_native(irregular, True) is None
+    for txt in ("1  2 3\n4 5 6", "1\t2 3\n4 5 6", "1_0 2 3", "1 2 3 4\n1 2 3", "1 2 NaN"):
+        assert util._xyz_native(txt, True) is None, txt
+    assert np.array_equal(util.xyz2tensor(" +1.5 2 3 \r\n4 5 6\n").numpy()[:, :3], [[1.5, 2, 3], [4, 5, 6]])
