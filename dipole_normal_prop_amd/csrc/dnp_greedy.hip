@@ -106,11 +106,30 @@ template <> struct Key<double> {
     }
 };
 
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+    return ((unsigned long long)dpp_u32<CTRL>((unsigned)(v >> 32)) << 32) | dpp_u32<CTRL>((unsigned)(v & 0xffffffffull));
+}
+template <int CTRL> __device__ __forceinline__ Key<float> key_dpp(const Key<float>& k) { return Key<float>{dpp_u64<CTRL>(k.k)}; }
+template <int CTRL> __device__ __forceinline__ Key<double> key_dpp(const Key<double>& k) {
+    return Key<double>{dpp_u64<CTRL>(k.a), dpp_u32<CTRL>(k.lo)};
+}
+
+// the wave's best key in every lane: four rounds on DPP (quad_perm lane^1, lane^2; row_half_mirror; row_mirror - all
+// register to register), two rounds across the 16-lane rows through ds_bpermute
 template <typename F>
 __device__ __forceinline__ Key<F> wave_best(Key<F> k) {
+    Key<F> o = key_dpp<0xB1>(k); if (o.beats(k)) k = o;
+    o = key_dpp<0x4E>(k); if (o.beats(k)) k = o;
+    o = key_dpp<0x141>(k); if (o.beats(k)) k = o;
+    o = key_dpp<0x140>(k); if (o.beats(k)) k = o;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const Key<F> o = k.xor_lane(off);
+    for (int off = 16; off <= 32; off <<= 1) {
+        o = k.xor_lane(off);
         if (o.beats(k)) k = o;
     }
     return k;
@@ -120,21 +139,49 @@ __device__ __forceinline__ Key<F> wave_best(Key<F> k) {
 // barrier of step-2, i.e. before every thread's arrival at the barrier of step-1, so thread 0 may clear it during
 // step; it is next written after this step's barrier).  fp64: one slot per wave, two sets by step parity (a set is
 // completely rewritten before its barrier, and its readers have passed the next barrier before that happens).
-template <typename F> struct ArgmaxLds;
-template <> struct ArgmaxLds<float> { unsigned long long word[3]; };
-template <> struct ArgmaxLds<double> { unsigned long long a[2][kGreedyWaves]; unsigned lo[2][kGreedyWaves]; };
+// Workgroup argmax, two forms.  0 (shipped): wave butterfly + one slot per wave in LDS.  1 (round 1, fp32 only): one
+// ds_max_u64 per lane on a single word - 512 atomics on one address serialise: 4.5 us per step on ok.xyz against
+// 3.1 us for the butterfly (tools/gpu_k4_ab.py, profiles/r02_greedy_time.txt).
+#ifndef DNP_K4_ATOMIC
+#define DNP_K4_ATOMIC 0
+#endif
+template <typename F> struct ArgmaxLds {
+    unsigned long long word[3];                      // fp32 atomic form
+    unsigned long long a[2][kGreedyWaves];           // butterfly form: one candidate per wave, two sets by step parity
+    unsigned lo[2][kGreedyWaves];
+};
+template <typename F> constexpr bool use_atomic_argmax() { return sizeof(F) == 4 && DNP_K4_ATOMIC; }
 
 template <typename F>
 __device__ __forceinline__ void argmax_init(ArgmaxLds<F>& s) {
-    if constexpr (sizeof(F) == 4) {
+    if constexpr (use_atomic_argmax<F>()) {
         if (threadIdx.x == 0) s.word[0] = s.word[1] = s.word[2] = 0ull;
     }
 }
 
+template <typename F> __device__ __forceinline__ void key_store(ArgmaxLds<F>& s, int par, int wave, const Key<F>& k);
+template <> __device__ __forceinline__ void key_store<float>(ArgmaxLds<float>& s, int par, int wave, const Key<float>& k) {
+    s.a[par][wave] = k.k;
+}
+template <> __device__ __forceinline__ void key_store<double>(ArgmaxLds<double>& s, int par, int wave, const Key<double>& k) {
+    s.a[par][wave] = k.a; s.lo[par][wave] = k.lo;
+}
+template <typename F> __device__ __forceinline__ Key<F> key_load(const ArgmaxLds<F>& s, int par, int q);
+template <> __device__ __forceinline__ Key<float> key_load<float>(const ArgmaxLds<float>& s, int par, int q) {
+    return Key<float>{s.a[par][q]};
+}
+template <> __device__ __forceinline__ Key<double> key_load<double>(const ArgmaxLds<double>& s, int par, int q) {
+    return Key<double>{s.a[par][q], s.lo[par][q]};
+}
+
 // every thread contributes `mine`; returns the workgroup's best key to every thread.  Contains ONE barrier.
+// Atomic form (fp32): three words in rotation - word (step+1)%3 was last read right after the barrier of step-2,
+// i.e. before every thread's arrival at the barrier of step-1, so thread 0 may clear it during step; it is next
+// written after this step's barrier.  Butterfly form: a set of wave slots is completely rewritten before its
+// barrier, and its readers have passed the next barrier before that happens, so two sets by step parity suffice.
 template <typename F>
 __device__ __forceinline__ Key<F> workgroup_best(ArgmaxLds<F>& s, Key<F> mine, int64_t step) {
-    if constexpr (sizeof(F) == 4) {
+    if constexpr (use_atomic_argmax<F>()) {
         const int par = (int)(step % 3);
         if (threadIdx.x == 0) s.word[(par + 1) % 3] = 0ull;
         if (mine.valid()) atomicMax(&s.word[par], mine.k);
@@ -142,13 +189,13 @@ __device__ __forceinline__ Key<F> workgroup_best(ArgmaxLds<F>& s, Key<F> mine, i
         return Key<float>{s.word[par]};
     } else {
         const int par = (int)(step & 1), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const Key<double> w = wave_best<double>(mine);
-        if (lane == 0) { s.a[par][wave] = w.a; s.lo[par][wave] = w.lo; }
+        const Key<F> w = wave_best<F>(mine);
+        if (lane == 0) key_store<F>(s, par, wave, w);
         __syncthreads();
-        Key<double> best = Key<double>::none();
+        Key<F> best = Key<F>::none();
 #pragma unroll
         for (int q = 0; q < kGreedyWaves; ++q) {
-            const Key<double> c{s.a[par][q], s.lo[par][q]};
+            const Key<F> c = key_load<F>(s, par, q);
             if (c.beats(best)) best = c;
         }
         return best;
