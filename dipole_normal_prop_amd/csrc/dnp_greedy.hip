@@ -523,10 +523,11 @@ static int run_point_greedy(F* pts, int64_t N, int64_t ld_pts, int64_t start, F 
     int* status = (int*)workspace;
     unsigned long long* slots = (unsigned long long*)((char*)workspace + kGreedyHeader);
     F* n_out = (F*)((char*)workspace + kGreedyHeader + kGreedySlots);
-    // Form selection: one workgroup keeps everything in registers but pays ~0.9 us per point-per-lane and step
-    // (IEEE div/sqrt chain); one workgroup per CU pays ~4 us per step for the granule all-gather.  Measured
-    // crossover between 2000 and 3000 points (fp32).
-    bool multi = (form == 2) || (form == 0 && N > 2048);
+    // Form selection: one workgroup keeps everything in registers but pays for every point per lane and step
+    // (IEEE div/sqrt chain: 1.1 us per step at 256 points, 2.4 at 2048, 4.2 at 4096 in fp32); one workgroup per CU
+    // pays 2.2-2.4 us per step (3 in fp64) for the granule all-gather whatever the size.  Measured crossover
+    // (tools/gpu_k4_forms.py): just below 2048 points in fp32, ~1500 in fp64.
+    bool multi = (form == 2) || (form == 0 && N > (sizeof(F) == 8 ? 1536 : 1792));
     if (form == 1) DNP_REQUIRE(N <= (int64_t)kGreedyThreads * kMaxPPT, "N=%lld exceeds the %d points of the single-workgroup form",
                                (long long)N, kGreedyThreads * kMaxPPT);
     if (N > (int64_t)kGreedyThreads * kMaxPPT) multi = true;

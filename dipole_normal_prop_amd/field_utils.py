@@ -877,7 +877,7 @@ def strongest_field_propagation_points(pts: torch.Tensor, diffuse=False, startin
         order = torch.empty(N, dtype=torch.int64, device=dev)
         done = False
         if N < lib.dnp_point_greedy_max_points() and N <= POINT_GREEDY_MAX_PER_GROUP[wd] * _cu_count(dev):
-            # one persistent launch: a single workgroup up to 2048 points, one workgroup per CU beyond
+            # one persistent launch: a single workgroup for small clouds, one workgroup per CU beyond ~1800 points
             nbytes = lib.dnp_point_greedy_workspace_bytes(N, work.element_size())
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             fn = lib.dnp_point_greedy_f64 if wd == torch.float64 else lib.dnp_point_greedy_f32
@@ -887,7 +887,7 @@ def strongest_field_propagation_points(pts: torch.Tensor, diffuse=False, startin
                         _lib.current_stream())
             _lib.check(rc)
             done = True
-            if N > 2048 and int(ws[:4].view(torch.int32).item()) != 0:
+            if int(ws[:4].view(torch.int32).item()) != 0:
                 # a workgroup of the multi-workgroup form gave up waiting for its peers (GPU shared with another
                 # process): the kernel left pts untouched; redo the propagation step by step
                 print("warning: persistent per-point kernel timed out, falling back to step-wise launches")
