@@ -6,10 +6,10 @@ the field dE_k of every patch on every other point can be evaluated before the g
 known (include/dnp.h, dnp_patch_fields_f32).  Every rank holds the full cloud (2.4 MB at 100 k
 points), evaluates a contiguous, size-balanced block of patches and its rows of the P x P
 interaction matrix W; ONE all-gather of the W rows (P*P*8 bytes = 512 KB at P = 256) gives every
-rank what rank 0 needs to run the whole sequential greedy loop as host arithmetic.  For the
-diffuse per-point pass the sign vector sigma[P] is then known on every rank (same W, same
-deterministic loop), each rank combines its own slabs, and one all-reduce (N*12 bytes) sums the
-partial fields.  No other collective is on the path.
+rank what the sequential greedy loop needs (it runs redundantly on every rank as the one-wavefront kernel
+dnp_patch_greedy: same W, deterministic).  For the diffuse per-point pass the sign vector sigma[P] is then
+known on every rank, each rank combines its own slabs in fp64, and one all-reduce (N*24 bytes) sums the
+partial fields; the start patch is rank 0's (8-byte broadcast).  No other collective is on the path.
 
 Reference lines: the loop being distributed is field_utils.py:308-335.
 """
