@@ -49,6 +49,7 @@ SIGNATURES = {
     "dnp_patch_greedy_max_patches": (ctypes.c_int, []),
     "dnp_patch_greedy": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "dnp_combine_signed_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, ctypes.c_int, _c_p]),
+    "dnp_patch_layout_f32": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p]),
     "dnp_patch_finish_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64,
                                             ctypes.c_int, _c_p]),
     "dnp_xyz_format_bound": (_c_i64, [_c_i64, _c_i64]),

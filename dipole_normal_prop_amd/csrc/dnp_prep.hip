@@ -214,6 +214,22 @@ __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restri
     }
 }
 
+// ---- the patch-sorted working layout in ONE launch: swork[i] = pts[idx[i]], sorted_patch[i] = p for the rows
+// i in [off[p], off[p+1]) of every patch p (one workgroup per patch); replaces a repeat_interleave (three launches), a
+// row gather and their temporaries in the drivers' set-up
+__global__ __launch_bounds__(256) void patch_layout_kernel(const float* __restrict__ pts, int64_t ld,
+                                                           const int64_t* __restrict__ off,
+                                                           const int64_t* __restrict__ idx, float* __restrict__ swork,
+                                                           int64_t* __restrict__ sorted_patch) {
+    const int64_t p = blockIdx.x, lo = off[p], hi = off[p + 1];
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const float* r = pts + idx[i] * ld;
+        float* o = swork + i * 6;
+        o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = r[4]; o[5] = r[5];
+        sorted_patch[i] = p;
+    }
+}
+
 // ---- the tail of the batched patch drivers in ONE launch (field_utils.py:322-323 flips, :337-342 diffuse sign pass,
 // :344-346 weight un-scaling), on the patch-sorted working cloud: for sorted row t
 //   n = work[t].n * sigma[patch(t)]                                    (patch(t) < 0: not in any patch, untouched)
@@ -342,6 +358,19 @@ int dnp_combine_signed_f32(const float* dE, int64_t K, int64_t N, const double* 
     const int64_t N3 = N * 3;
     hipLaunchKernelGGL(combine_signed_kernel, dim3((unsigned)ceil_div(N3, 256)), dim3(256), 0, (hipStream_t)stream,
                        dE, K, N3, sigma ? sigma + p_lo : nullptr, E, accumulate);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+int dnp_patch_layout_f32(const float* pts, int64_t ld_pts, const int64_t* patch_off, const int64_t* patch_idx,
+                         int64_t P, float* swork, int64_t* sorted_patch, void* stream) {
+    clear_error();
+    DNP_REQUIRE(P >= 0, "negative P");
+    if (P == 0) return DNP_OK;
+    DNP_REQUIRE(pts && patch_off && patch_idx && swork && sorted_patch, "NULL pointer");
+    DNP_REQUIRE(ld_pts >= 6, "ld_pts=%lld < 6", (long long)ld_pts);
+    hipLaunchKernelGGL(patch_layout_kernel, dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pts, ld_pts, patch_off,
+                       patch_idx, swork, sorted_patch);
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
 }

@@ -605,17 +605,27 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
     # data layout for the kernels: the cloud sorted by patch (points in no patch last), so that a patch
     # is a contiguous row range - sources stream linearly and K3 reads its slab rows coalesced
     covered = int(sizes.sum())
-    point_patch = torch.repeat_interleave(torch.arange(P, device=dev), util.to_device(sizes, dev),
-                                          output_size=covered)
-    if covered == N:
+    if covered == N and work.is_cuda and work.dtype == torch.float32:
+        # every point is in a patch (the callers' case): one launch builds the sorted cloud and its patch ids
         perm = idx
+        swork = torch.empty((N, 6), dtype=torch.float32, device=dev)
+        point_patch = torch.empty(N, dtype=torch.int64, device=dev)
+        with _on_device(dev):
+            _lib.check(_lib.require_device().dnp_patch_layout_f32(_lib.ptr(work), work.stride(0), _lib.ptr(off),
+                                                                   _lib.ptr(idx), P, _lib.ptr(swork), _lib.ptr(point_patch),
+                                                                   _lib.current_stream()))
     else:
-        seen = torch.zeros(N, dtype=torch.bool, device=dev)
-        seen[idx] = True
-        loose = torch.nonzero(~seen).flatten()
-        perm = torch.cat([idx, loose])
-        point_patch = torch.cat([point_patch, torch.full((loose.shape[0],), -1, dtype=torch.int64, device=dev)])
-    swork = work[perm].contiguous()
+        point_patch = torch.repeat_interleave(torch.arange(P, device=dev), util.to_device(sizes, dev),
+                                              output_size=covered)
+        if covered == N:
+            perm = idx
+        else:
+            seen = torch.zeros(N, dtype=torch.bool, device=dev)
+            seen[idx] = True
+            loose = torch.nonzero(~seen).flatten()
+            perm = torch.cat([idx, loose])
+            point_patch = torch.cat([point_patch, torch.full((loose.shape[0],), -1, dtype=torch.int64, device=dev)])
+        swork = work[perm].contiguous()
 
     rank, world, gather = (0, 1, None) if shard is None else shard
     # contiguous blocks of patches per rank, balanced by pair count |patch| * N

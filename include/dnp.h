@@ -206,6 +206,15 @@ int dnp_patch_greedy(const double* W, int64_t P, const int64_t* start, int64_t* 
 int dnp_combine_signed_f32(const float* dE, int64_t K, int64_t N, const double* sigma, int64_t P, int64_t p_lo,
                            double* E, int accumulate, void* stream);
 
+/* ---- patch-sorted working layout  (the set-up of the batched drivers) -----------------------------------------
+ *
+ * swork[i] = pts[patch_idx[i]] (6 floats per row) and sorted_patch[i] = p for the rows i in
+ * [patch_off[p], patch_off[p+1]) of every patch p: the cloud sorted by patch, in which a patch is a contiguous row
+ * range (what dnp_patch_fields_f32 with patch_idx == NULL expects).  swork is [patch_off[P], 6] floats.
+ */
+int dnp_patch_layout_f32(const float* pts, int64_t ld_pts, const int64_t* patch_off, const int64_t* patch_idx,
+                         int64_t P, float* swork, int64_t* sorted_patch, void* stream);
+
 /* ---- tail of the batched patch drivers in one launch (field_utils.py:322-323, :337-342, :344-346) ----------
  *
  * On the patch-sorted working cloud work[N, >=6] (fp32, normals possibly weight-scaled), for sorted row t:
