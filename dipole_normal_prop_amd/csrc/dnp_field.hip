@@ -25,8 +25,11 @@ namespace dnp {
 #ifndef DNP_MINCHUNK_DIV
 #define DNP_MINCHUNK_DIV 512
 #endif
+#ifndef DNP_LDS_MINCHUNK_DIV
+#define DNP_LDS_MINCHUNK_DIV 64
+#endif
 static inline int64_t min_chunk(int64_t S, bool scalar_kernel) {
-    const int64_t m = S / (scalar_kernel ? DNP_MINCHUNK_DIV : 64);
+    const int64_t m = S / (scalar_kernel ? DNP_MINCHUNK_DIV : DNP_LDS_MINCHUNK_DIV);
     return m < 64 ? 64 : (m > DNP_MINCHUNK_CAP ? DNP_MINCHUNK_CAP : m);
 }
 constexpr int kKTScalar = 2, kKTLds = 4;

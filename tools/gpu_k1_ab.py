@@ -34,7 +34,10 @@ def main():
     clouds = {"fandisk": torch.from_numpy(load_golden("G5_fandisk_allpairs")["pc"]).to(dev), "sphere3k": sphere(3000).to(dev),
               "sphere30k": sphere(30000).to(dev), "sphere100k": sphere(100000).to(dev)}
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    only = [c for c in os.environ.get("K1_CLOUDS", "").split(",") if c]
     for cname, pc in clouds.items():
+        if only and cname not in only:
+            continue
         n = pc.shape[0]
         out = torch.empty(n, 3, device=dev)
         ws = {k: torch.empty(lib.dnp_field_grad_workspace_bytes(n, n, 15000), dtype=torch.uint8, device=dev) for k, lib in libs.items()}
