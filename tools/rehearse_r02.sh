@@ -1,0 +1,17 @@
+set +e
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+OUT=gpurun_out/rehearsal.txt
+: > $OUT
+for N in 2 4; do
+  echo "## torch.distributed.run --nproc-per-node $N bench.py --gpus $N --steps 5 --warmup 2  (BENCH_BACKEND=gloo)" >> $OUT
+  BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2950$N bench.py --gpus $N --steps 5 --warmup 2 --no-cpu-baseline --headline-only 2>/dev/null | grep '^{' >> $OUT
+  echo >> $OUT
+done
+S=gpurun_out/rank_share.txt
+: > $S
+for N in 1 2 4 8; do
+  BENCH_FAKE_WORLD=$N timeout -k 10 200 python bench.py --no-cpu-baseline --headline-only --steps 50 --warmup 5 2>/dev/null | grep '^{' | python -c "
+import json,sys
+b=json.loads(sys.stdin.read()); print($N, round(b['ms_per_step'],4), round(b['roofline']['launch_ms'],4))" >> $S
+done
+cat $S
