@@ -1,0 +1,164 @@
+// AddressSanitizer / UBSan fuzz of the HOST functions of libdnp (CPU build of csrc/dnp_io.hip and csrc/dnp_prep.hip;
+// GPU sanitizers are not available on the pool).  Built and run by tests/test_host_sanitized.py.
+//   dnp_xyz_parse_f32 / dnp_xyz_format_f32: random bytes, random number-alphabet text and mutated well-formed rows in
+//     exact-size heap buffers (an over-read trips ASan); every accepted text must survive format -> parse unchanged.
+//   dnp_merge_cells: random voxel sets against a brute-force restatement of the merge rule (include/dnp.h).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "dnp.h"
+
+static int fuzz_text(std::mt19937_64& rng, int iterations) {
+    const char alphabet[] = "0123456789.eE+- \n\t\rnaif_x";
+    long parsed = 0, rejected = 0;
+    for (int it = 0; it < iterations; ++it) {
+        std::string s(rng() % 200, ' ');
+        const int mode = (int)(rng() % 3);
+        if (mode == 0) {
+            for (auto& c : s) c = alphabet[rng() % (sizeof(alphabet) - 1)];
+        } else if (mode == 1) {
+            for (auto& c : s) c = (char)(rng() & 0xff);
+        } else {
+            s.clear();
+            const int rows = (int)(rng() % 6), cols = (rng() & 1) ? 3 : 6;
+            for (int r = 0; r < rows; ++r) {
+                for (int c = 0; c < cols; ++c) {
+                    char b[40];
+                    snprintf(b, sizeof b, "%.9g", (double)(int64_t)(rng() % 2000000) / 1e3 - 1e3);
+                    s += b;
+                    if (c + 1 < cols) s += " ";
+                }
+                s += "\n";
+            }
+            if (!s.empty() && (rng() & 3) == 0) s[rng() % s.size()] = alphabet[rng() % (sizeof(alphabet) - 1)];
+        }
+        char* txt = (char*)malloc(s.size() ? s.size() : 1);
+        memcpy(txt, s.data(), s.size());
+        int32_t ncol = 0;
+        const int64_t max_rows = (int64_t)(rng() % 8);
+        float* out = (float*)malloc(sizeof(float) * 6 * (size_t)(max_rows ? max_rows : 1));
+        const int64_t n = dnp_xyz_parse_f32(txt, (int64_t)s.size(), out, max_rows, &ncol);
+        if (n > 0) {
+            ++parsed;
+            const int64_t cap = dnp_xyz_format_bound(n, ncol);
+            char* o = (char*)malloc((size_t)cap);
+            const int64_t w = dnp_xyz_format_f32(out, n, ncol, o, cap);
+            if (w < 0 || w > cap) { printf("format wrote %lld of %lld\n", (long long)w, (long long)cap); return 1; }
+            std::vector<float> back((size_t)(n * ncol));
+            int32_t nc2 = 0;
+            const int64_t n2 = dnp_xyz_parse_f32(o, w, back.data(), n, &nc2);
+            if (n2 != n || nc2 != ncol || memcmp(back.data(), out, sizeof(float) * (size_t)(n * ncol)) != 0) {
+                printf("format -> parse changed the values\n");
+                return 1;
+            }
+            free(o);
+        } else {
+            ++rejected;
+        }
+        free(out);
+        free(txt);
+    }
+    std::vector<float> ext;                                   // every bit pattern class through the formatter
+    for (int i = 0; i < 40000; ++i) {
+        const uint32_t b = (uint32_t)rng();
+        float f;
+        memcpy(&f, &b, 4);
+        ext.push_back(f);
+    }
+    const int64_t cap = dnp_xyz_format_bound((int64_t)ext.size() / 4, 4);
+    char* o = (char*)malloc((size_t)cap);
+    const int64_t w = dnp_xyz_format_f32(ext.data(), (int64_t)ext.size() / 4, 4, o, cap);
+    free(o);
+    printf("text: %ld accepted, %ld rejected / empty; %lld of %lld bytes for random bit patterns\n", parsed, rejected,
+           (long long)w, (long long)cap);
+    return (w > 0 && w <= cap) ? 0 : 1;
+}
+
+// brute-force statement of the merge rule: live cells own voxel lists; adjacency by scanning every voxel pair
+static void merge_brute(const std::vector<int32_t>& ijk, const std::vector<int64_t>& sz, int64_t min_patch,
+                        std::vector<int64_t>& seq, std::vector<int64_t>& off) {
+    const int64_t C = (int64_t)sz.size();
+    std::vector<std::vector<int32_t>> members((size_t)C);
+    std::vector<int64_t> size(sz);
+    for (int64_t c = 0; c < C; ++c) members[(size_t)c].push_back((int32_t)c);
+    auto touches = [&](int32_t a, int32_t b) {
+        for (int d = 0; d < 3; ++d)
+            if (abs(ijk[(size_t)a * 3 + d] - ijk[(size_t)b * 3 + d]) > 1) return false;
+        return true;
+    };
+    bool again = true;
+    for (int sweep = 0; again && sweep < 10; ++sweep) {
+        again = false;
+        for (int64_t i = 0; i < C; ++i) {
+            if (members[(size_t)i].empty() || size[(size_t)i] >= min_patch) continue;
+            int64_t target = -1;
+            for (int64_t j = 0; j < C; ++j) {
+                if (j == i || members[(size_t)j].empty()) continue;
+                bool adj = false;
+                for (int32_t a : members[(size_t)i])
+                    for (int32_t b : members[(size_t)j]) adj = adj || touches(a, b);
+                if (adj) target = j;                          // the last match wins
+            }
+            if (target < 0) continue;
+            for (int32_t a : members[(size_t)i]) members[(size_t)target].push_back(a);
+            size[(size_t)target] += size[(size_t)i];
+            size[(size_t)i] = 0;
+            members[(size_t)i].clear();
+            if (size[(size_t)target] < min_patch) again = true;
+        }
+    }
+    seq.clear();
+    off.assign(1, 0);
+    for (int64_t i = 0; i < C; ++i) {
+        if (members[(size_t)i].empty() || size[(size_t)i] < min_patch) continue;
+        for (int32_t a : members[(size_t)i]) seq.push_back(a);
+        off.push_back((int64_t)seq.size());
+    }
+}
+
+static int fuzz_merge(std::mt19937_64& rng, int iterations) {
+    for (int it = 0; it < iterations; ++it) {
+        const int side = 2 + (int)(rng() % 5);
+        std::vector<int32_t> ijk;
+        std::vector<int64_t> sz;
+        for (int i = 0; i < side; ++i)                        // (i, j, k)-lexicographic order, some cells empty
+            for (int j = 0; j < side; ++j)
+                for (int k = 0; k < side; ++k)
+                    if (rng() % 3) {
+                        ijk.insert(ijk.end(), {i, j, k});
+                        sz.push_back((int64_t)(rng() % 40));
+                    }
+        const int64_t C = (int64_t)sz.size(), min_patch = (int64_t)(rng() % 60);
+        // exact-size heap buffers
+        int32_t* h_ijk = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)(C ? C : 1));
+        int64_t* h_sz = (int64_t*)malloc(sizeof(int64_t) * (size_t)(C ? C : 1));
+        int64_t* h_seq = (int64_t*)malloc(sizeof(int64_t) * (size_t)(C ? C : 1));
+        int64_t* h_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(C + 1));
+        memcpy(h_ijk, ijk.data(), sizeof(int32_t) * ijk.size());
+        memcpy(h_sz, sz.data(), sizeof(int64_t) * sz.size());
+        int64_t n = -1;
+        int32_t sweeps = -1;
+        const int rc = dnp_merge_cells(h_ijk, h_sz, C, min_patch, h_seq, h_off, &n, &sweeps);
+        std::vector<int64_t> seq, off;
+        merge_brute(ijk, sz, min_patch, seq, off);
+        bool ok = rc == 0 && n == (int64_t)off.size() - 1 && sweeps >= 1 && sweeps <= 10;
+        for (size_t q = 0; ok && q < off.size(); ++q) ok = h_off[q] == off[q];
+        for (size_t q = 0; ok && q < seq.size(); ++q) ok = h_seq[q] == seq[q];
+        free(h_ijk); free(h_sz); free(h_seq); free(h_off);
+        if (!ok) { printf("merge mismatch at iteration %d (C=%lld, min_patch=%lld)\n", it, (long long)C, (long long)min_patch); return 1; }
+    }
+    printf("merge: %d random voxel sets equal the brute-force rule\n", iterations);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const int scale = argc > 1 ? atoi(argv[1]) : 1;
+    std::mt19937_64 rng(1234);
+    if (fuzz_text(rng, 40000 * scale)) return 1;
+    if (fuzz_merge(rng, 300 * scale)) return 1;
+    return 0;
+}
