@@ -148,6 +148,40 @@ def test_headline_size_patch_propagation_on_boxunion(dev):
     assert np.array_equal(sign, g17["sign"])
 
 
+def test_config5_reference_field_at_headline_size(dev):
+    """BASELINE config 5 (reference_field, field_utils.py:188-201) with S = T = 100 000 on a reference-held cloud:
+    the G15 boxunion cloud orients its own 1e-3-jittered, sign-scrambled copy - 10^10 pair evaluations in the
+    reference (G18, ~15 minutes on the build container, targets fed in row blocks).  All 100 000 sign decisions,
+    bit for bit except where the reference's own E.n is below fp32 summation noise; fields and the 3-column-form
+    normals on 4000 sampled rows within 1e-5."""
+    g15, g = load_golden("G15_boxunion_config3"), load_golden("G18_reference_field_100k")
+    src = torch.from_numpy(g15["pc"]).clone()
+    N = src.shape[0]
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    tgt3 = (src[:, :3] + 1e-3 * torch.randn(N, 3, generator=gen)).contiguous()
+    assert np.array_equal(tgt3[:8].numpy(), g["tgt3_head"]) and np.allclose(tgt3.double().sum(0).numpy(), g["tgt3_sum"], rtol=0, atol=1e-9)
+    flip = torch.rand(N, generator=torch.Generator().manual_seed(int(g["seed"]))) < 0.5
+    assert int(flip.sum()) == int(g["flip_count"])                      # the golden's inputs, rebuilt from the seed
+    tgt6 = torch.cat([tgt3, src[:, 3:]], dim=1)
+    tgt6[flip, 3:] *= -1
+    src_d = src.to(dev)
+    work = tgt6.clone().to(dev)
+    out6 = fu.reference_field(src_d, work)
+    assert out6.data_ptr() == work.data_ptr()                           # 6-column form orients in place
+    keep = ((out6.cpu()[:, 3:] * tgt6[:, 3:]).sum(-1) > 0).numpy()
+    ref_keep = np.unpackbits(g["keep"])[:N].astype(bool)
+    E = fu.field_grad(src_d, tgt3.to(dev)).cpu().numpy()
+    differ = np.nonzero(keep != ref_keep)[0]
+    # a decision may differ only where the reference's E.n is itself rounding noise of its fp32 sum over 10^5 sources
+    assert len(differ) <= 5 and np.all(np.abs(g["e_dot_n"][differ]) <= 1e-5 * np.linalg.norm(E[differ], axis=1)), differ
+    rows = g["rows"]
+    scale = np.linalg.norm(g["E_rows"], axis=1, keepdims=True)
+    assert (np.abs(E[rows] - g["E_rows"]) / scale).max() < 1e-5
+    out3 = fu.reference_field(src_d, tgt3[rows].to(dev)).cpu().numpy()
+    assert out3.shape == (len(rows), 6) and np.array_equal(out3[:, :3], tgt3[rows].numpy())
+    assert np.abs(out3[:, 3:] - g["out3_rows"][:, 3:]).max() < 1e-5
+
+
 def test_config3_boxunion_default_start_reaches_the_same_orientation(dev):
     """Without the pin the driver starts from the first exactly-flat patch (another member of the reference's tie
     class), visits the patches in a different order - and must still end, after the global potential fix, with the

@@ -96,6 +96,27 @@ def test_G9_reference_field():
     assert np.array_equal(out6, g["out6"])                   # sign decisions identical
 
 
+def test_G18_reference_field_100k_sampled_rows():
+    """Config 5 at S = T = 100 000 (G18): the oracle on the first 256 sampled target rows of the golden - field within
+    1e-5, the sign decisions of those rows identical wherever the reference's E.n is above noise."""
+    g15, g = load_golden("G15_boxunion_config3"), load_golden("G18_reference_field_100k")
+    src = t(g15["pc"]).clone()
+    N = src.shape[0]
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    tgt3 = (src[:, :3] + 1e-3 * torch.randn(N, 3, generator=gen)).contiguous()
+    assert np.array_equal(tgt3[:8].numpy(), g["tgt3_head"])
+    flip = torch.rand(N, generator=torch.Generator().manual_seed(int(g["seed"]))) < 0.5
+    rows = t(g["rows"][:256].astype(np.int64))
+    E = O.field_grad(src, tgt3[rows]).numpy()
+    ref = g["E_rows"][:256]
+    assert (np.abs(E - ref) / np.linalg.norm(ref, axis=1, keepdims=True)).max() < 1e-5
+    n = src[rows, 3:] * torch.where(flip[rows], -1.0, 1.0)[:, None]
+    keep = (E * n.numpy()).sum(-1) >= 0
+    ref_keep = np.unpackbits(g["keep"])[:N].astype(bool)[rows.numpy()]
+    clear = np.abs(g["e_dot_n"][rows.numpy()]) > 1e-5 * np.linalg.norm(ref, axis=1)
+    assert np.array_equal(keep[clear], ref_keep[clear]) and clear.mean() > 0.99
+
+
 def test_G10_edge_weight():
     g = load_golden("G10_edge")
     w, invw = O.field_edge_calculator(t(g["a"]), t(g["b"]))

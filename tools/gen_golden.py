@@ -741,6 +741,39 @@ def g17(fu, util):
          curv=np.array([util.pca_eigen_values(pc[p])[0].item() for p in allp]))
 
 
+def g18(fu, util):
+    """BASELINE config 5 at its headline size on a reference-held cloud: reference_field (field_utils.py:188-201)
+    with S = T = 100 000 - the G15 boxunion cloud as the oriented reference, the same cloud jittered by 1e-3
+    (seed 5) as the cloud to orient, normals sign-scrambled (seed 5).  10^10 pair evaluations.  The reference's
+    field_grad splits only the SOURCES into leaves, so one call would hold [100 000, 12 500, 3] temporaries
+    (15 GB each); the harness feeds the targets in blocks of 4000 rows - every target row is an independent sum,
+    so this is the call the reference makes, row block by row block.  Stored: the sign decision of all 100 000
+    points (6-column form), E.n of every point (the margin of that decision), the field and the 3-column-form
+    normals on 4000 sampled rows.  Inputs are rebuilt from G15 and the seed."""
+    g = np.load(os.path.join(OUT, "G15_boxunion_config3.npz"))
+    src = torch.from_numpy(g["pc"]).clone()
+    gen = torch.Generator().manual_seed(5)
+    tgt3 = (src[:, :3] + 1e-3 * torch.randn(src.shape[0], 3, generator=gen)).contiguous()
+    tgt6, flip = scramble_signs(torch.cat([tgt3, src[:, 3:]], dim=1), 5)
+    N = src.shape[0]
+    rows = torch.sort(torch.randperm(N, generator=gen)[:4000]).values
+    t0 = time.time()
+    out6 = torch.empty_like(tgt6)
+    E = torch.empty(N, 3)
+    for lo in range(0, N, 4000):
+        blk = tgt6[lo:lo + 4000].clone()
+        E[lo:lo + 4000] = fu.field_grad(src, blk)                      # the field reference_field computes first
+        out6[lo:lo + 4000] = fu.reference_field(src, blk)             # in place on the block, returned
+        if (lo // 4000) % 5 == 0:
+            print(f"    rows {lo}: {time.time() - t0:.0f}s", flush=True)
+    out3_rows = fu.reference_field(src, tgt3[rows].clone())
+    print(f"  reference_field at 100k x 100k: {time.time() - t0:.1f}s")
+    keep = (out6[:, 3:] * tgt6[:, 3:]).sum(-1) > 0                     # sign = +1 rows
+    save("G18_reference_field_100k", seed=5, tgt3_head=tgt3[:8], tgt3_sum=tgt3.double().sum(0), flip_count=int(flip.sum()),
+         keep=np.packbits(keep.numpy()), e_dot_n=(E * tgt6[:, 3:]).sum(-1), rows=rows, E_rows=E[rows],
+         out3_rows=out3_rows)
+
+
 def make_inference_shim():
     """inference_utils.py imports models/ (torch_geometric, absent offline) at module level.
     Only its pure-torch fix_n_filter is on the path; load that one function's source object by
@@ -756,7 +789,7 @@ def make_inference_shim():
     spec.loader.exec_module(mod)
 
 
-ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13, G14=g14, G15=g15, G16=g16, GW=gw, GX2=gx2, G17=g17)
+ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13, G14=g14, G15=g15, G16=g16, GW=gw, GX2=gx2, G17=g17, G18=g18)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
