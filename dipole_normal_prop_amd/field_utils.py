@@ -137,55 +137,81 @@ def _pairs_into(kind: str, src, src_idx, tgt, tgt_idx, eps, max_pts, out, out_sc
 
 
 # ---- the reference's "warning: %d inf in field_grad" prints (field_utils.py:110-113) -----------------------------
-# The kernels count the Inf / NaN leaf components they zero into a three-int slot {inf, nan, stamp = 1} of a small
-# device ring; the library copies the slot to pinned host memory asynchronously behind the kernels, and the host
-# copy's stamp says when it has landed.  Per call this costs pointer arithmetic only.  The line is printed as soon
-# as a later call on this thread finds the copy landed - at the latest by flush_warnings() or interpreter exit -
-# so that a field_grad call never waits for the device just to find out that there is nothing to warn about.
+# The kernels count the Inf / NaN leaf components they zero into a three-int slot {inf, nan, spare} of a small
+# device ring, one slot per field_grad call.  Nothing is copied per call: after every _WARN_BATCH calls ONE
+# asynchronous copy moves that block of slots to pinned host memory behind the kernels (and re-arms the block), an
+# event says when it has landed, and the lines are printed by the next call on this thread that finds it landed -
+# at the latest by flush_warnings() or interpreter exit.  A field_grad call therefore never waits for the device,
+# and never launches a copy of its own, just to find out that there is nothing to warn about.
 _WARN_RING = 64
+_WARN_BATCH = 16
 
 
 class _WarnState:
     def __init__(self, dev):
         self.dev = dev
         self.ring = torch.zeros((_WARN_RING, 3), dtype=torch.int32, device=dev)
-        self.ring[:, 2] = 1                                           # the "landed" stamp
         self.host = torch.zeros((_WARN_RING, 3), dtype=torch.int32).pin_memory()
         self.view = self.host.numpy()
-        self.dev_base, self.host_base = self.ring.data_ptr(), self.host.data_ptr()
+        self.dev_base = self.ring.data_ptr()
         self.head = 0             # next slot to hand out
+        self.copied = 0           # slots below this have their copy to the host enqueued
         self.tail = 0             # oldest slot not yet reported
+        self.batches = []         # (event, lo, hi) of the copies in flight, oldest first
+        self.stream = None        # stream of the calls since the last copy; False once they used more than one
         self.lock = threading.Lock()   # flush_warnings() may drain this state from another thread
         torch.cuda.current_stream(dev).synchronize()                  # the ring is initialised before its first use
 
-    def next_slot(self):
+    def next_slot(self, stream):
+        """(device pointer, None) of the slot of one call launched on `stream` (an integer handle)."""
         if self.head - self.tail >= _WARN_RING:                       # every slot is in flight: wait for the oldest
             self.drain(block=True)
         with self.lock:
             i = self.head % _WARN_RING
             self.head += 1
-        return (ctypes.c_void_p(self.dev_base + 12 * i), ctypes.c_void_p(self.host_base + 12 * i))
+            if self.stream is None:
+                self.stream = stream
+            elif self.stream != stream:
+                self.stream = False
+        return (ctypes.c_void_p(self.dev_base + 12 * i), None)
+
+    def _enqueue_copy(self):
+        """Copy slots [copied, head) to the host behind the kernels that fill them, re-arm them, remember the event."""
+        lo, hi = self.copied, self.head
+        if lo == hi:
+            return
+        with _on_device(self.dev):
+            if self.stream is False:                                  # calls on several streams: order them all first
+                torch.cuda.synchronize(self.dev)
+            a, b = lo % _WARN_RING, (hi - 1) % _WARN_RING + 1
+            for x, y in ([(a, b)] if a < b else [(a, _WARN_RING), (0, b)]):
+                self.host[x:y].copy_(self.ring[x:y], non_blocking=True)
+                self.ring[x:y].zero_()
+            ev = torch.cuda.Event()
+            ev.record()
+        self.batches.append((ev, lo, hi))
+        self.copied, self.stream = hi, None
+
+    def after_call(self):
+        with self.lock:
+            if self.head - self.copied >= _WARN_BATCH:
+                self._enqueue_copy()
 
     def drain(self, block=False):
-        if block and self.tail < self.head:
-            torch.cuda.synchronize(self.dev)
         with self.lock:
-            self._drain_landed()
-
-    def _drain_landed(self):
-        while self.tail < self.head:
-            i = self.tail % _WARN_RING
-            if self.view[i, 2] != 1:
-                break                                                 # not landed yet (copies land in order)
-            n_inf, n_nan = int(self.view[i, 0]), int(self.view[i, 1])
-            if n_inf:
-                print("warning: %d inf in field_grad" % n_inf)
-            if n_nan:
-                print("warning: %d nan in field_grad" % n_nan)
-            if n_inf or n_nan:
-                self.ring[i, :2] = 0                                  # rare: re-arm the slot's counters
-            self.view[i, :] = 0
-            self.tail += 1
+            if block:
+                torch.cuda.synchronize(self.dev)                      # also orders calls made on other streams
+                self._enqueue_copy()
+            while self.batches and (block or self.batches[0][0].query()):
+                ev, lo, hi = self.batches.pop(0)
+                ev.synchronize()
+                for k in range(lo, hi):
+                    n_inf, n_nan = int(self.view[k % _WARN_RING, 0]), int(self.view[k % _WARN_RING, 1])
+                    if n_inf:
+                        print("warning: %d inf in field_grad" % n_inf)
+                    if n_nan:
+                        print("warning: %d nan in field_grad" % n_nan)
+                self.tail = hi
 
 
 _warn_states = []
@@ -232,8 +258,11 @@ def _field_like(kind, sources, means, eps, recursive, max_pts):
         if kind == "field" and src.shape[0] > 0:
             # the reference prints (never raises) when a leaf produced Inf/NaN, then zeroes them
             st = _warn_state(dev)
-            st.drain()
-            _pairs_into(kind, src, None, tgt, None, eps, max_pts if recursive else 0, out, nonfinite=st.next_slot())
+            if st.batches:
+                st.drain()
+            slot = st.next_slot(torch.cuda.current_stream(dev).cuda_stream)
+            _pairs_into(kind, src, None, tgt, None, eps, max_pts if recursive else 0, out, nonfinite=slot)
+            st.after_call()
         else:
             _pairs_into(kind, src, None, tgt, None, eps, max_pts if recursive else 0, out)
     return out.to(device=in_dev, dtype=in_dtype) if (out.device != in_dev or out.dtype != in_dtype) else out

@@ -754,3 +754,22 @@ def test_nonfinite_leaf_components_are_counted_and_zeroed(dev, capsys):
     fu.field_grad(src.to(dev), tgt.to(dev))            # eps > 0: the coincident pair contributes 0, no warning
     fu.flush_warnings()
     assert "field_grad" not in capsys.readouterr().out
+    # the counters travel to the host in blocks of 16 calls, printed by a later call without any explicit flush;
+    # slots are recycled correctly over several turns of the 64-slot ring
+    small_s, small_t = src[:300].to(dev), tgt[10:18].to(dev)      # rows without a coincident source
+    bad_t = small_t.clone()
+    bad_t[2] = small_s[7, :3]
+    expected = 0
+    for k in range(200):
+        if k % 37 == 5:
+            fu.field_grad(small_s, bad_t, eps=0.0)
+            expected += 1
+        else:
+            fu.field_grad(small_s, small_t, eps=0.0)
+    torch.cuda.synchronize()
+    for _ in range(17):                                # one more block of calls: finds every earlier block landed
+        fu.field_grad(small_s, small_t, eps=0.0)
+    lazily = capsys.readouterr().out.count("warning: 3 nan in field_grad")
+    assert lazily == expected, (lazily, expected)
+    fu.flush_warnings()
+    assert "field_grad" not in capsys.readouterr().out
