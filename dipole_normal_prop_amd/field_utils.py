@@ -80,13 +80,13 @@ def _on_device(dev):
 _tls = threading.local()
 
 
-def _workspace(nbytes: int, dev: torch.device) -> torch.Tensor:
+def _workspace(nbytes: int, dev: torch.device, stream_handle=None) -> torch.Tensor:
     """Scratch for one launch sequence, cached per (thread, device, stream): work on one stream is
     ordered, so the next call on that stream may overwrite it; other streams / threads get their own."""
     cache = getattr(_tls, "ws", None)
     if cache is None:
         cache = _tls.ws = {}
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream if stream_handle is None else stream_handle)
     buf = cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = cache[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
@@ -107,21 +107,32 @@ def _idx(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
     return t.to(device=dev, dtype=torch.int64).contiguous()
 
 
+_WS_BYTES = {}
+
+
 def _pairs_into(kind: str, src, src_idx, tgt, tgt_idx, eps, max_pts, out, out_scatter=False, accumulate=False,
-                nonfinite=(None, None)):
+                nonfinite=(None, None), stream_handle=None):
     """Launch K1/K2 on staged device tensors.  src/tgt/out live on the compute device.  nonfinite = (device
-    pointer, pinned host pointer) of the three-int warning slot of this call, as ctypes pointers or None."""
+    pointer, pinned host pointer) of the three-int warning slot of this call, as ctypes pointers or None;
+    stream_handle = the device's current stream when the caller has looked it up already."""
     lib = _lib.require_device()
     S = src.shape[0] if src_idx is None else src_idx.shape[0]
     T = tgt.shape[0] if tgt_idx is None else tgt_idx.shape[0]
     f64 = src.dtype == torch.float64
-    if kind == "field":
-        nbytes = lib.dnp_field_grad_workspace_bytes(S, T, max_pts)
-    else:
-        nbytes = lib.dnp_potential_workspace_bytes(S, T, max_pts)
-    ws = _workspace(nbytes, src.device)
+    nbytes = _WS_BYTES.get((kind, S, T, max_pts))
+    if nbytes is None:                                  # a pure function of the sizes: asked once per shape
+        if len(_WS_BYTES) > 4096:
+            _WS_BYTES.clear()
+        if kind == "field":
+            nbytes = lib.dnp_field_grad_workspace_bytes(S, T, max_pts)
+        else:
+            nbytes = lib.dnp_potential_workspace_bytes(S, T, max_pts)
+        _WS_BYTES[(kind, S, T, max_pts)] = nbytes
+    if stream_handle is None:
+        stream_handle = torch.cuda.current_stream(src.device).cuda_stream
+    ws = _workspace(nbytes, src.device, stream_handle)
     with _on_device(src.device):
-        stream = _lib.current_stream()
+        stream = ctypes.c_void_p(stream_handle)
         if kind == "field":
             fn = lib.dnp_field_grad_f64 if f64 else lib.dnp_field_grad_f32
             rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(src_idx), _lib.ptr(tgt), T, _ld(tgt), _lib.ptr(tgt_idx),
@@ -260,8 +271,9 @@ def _field_like(kind, sources, means, eps, recursive, max_pts):
             st = _warn_state(dev)
             if st.batches:
                 st.drain()
-            slot = st.next_slot(torch.cuda.current_stream(dev).cuda_stream)
-            _pairs_into(kind, src, None, tgt, None, eps, max_pts if recursive else 0, out, nonfinite=slot)
+            handle = torch.cuda.current_stream(dev).cuda_stream
+            _pairs_into(kind, src, None, tgt, None, eps, max_pts if recursive else 0, out,
+                        nonfinite=st.next_slot(handle), stream_handle=handle)
             st.after_call()
         else:
             _pairs_into(kind, src, None, tgt, None, eps, max_pts if recursive else 0, out)
