@@ -38,6 +38,8 @@ __all__ = [
 PATCH_MODE = "auto"
 # device bytes the batched drivers may spend on the [P, N, 3] slab before they fall back to two passes
 SLAB_BUDGET_BYTES = 48 << 30
+# block size of the slab evaluation once the slabs do not fit that budget at once
+SLAB_BLOCK_BYTES = 16 << 30
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -673,18 +675,29 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
     bounds = _balanced_blocks(sizes, world)
     p_lo, p_hi = int(bounds[rank]), int(bounds[rank + 1])
 
+    # Slab memory: every patch's field on all N points is 12 N bytes.  Within SLAB_BUDGET_BYTES all slabs of this rank
+    # are evaluated by one launch and kept for the diffuse combine.  Beyond it the budget is raised to 80 % of what
+    # the device has free (288 GB of HBM on an MI355X), the patches go through in blocks of at most SLAB_BLOCK_BYTES,
+    # as many blocks as fit are kept, and only the others are evaluated a second time for the combine.
     per_slab = N * 3 * 4
-    batch = max(1, min(max(p_hi - p_lo, 1), SLAB_BUDGET_BYTES // max(per_slab, 1)))
-    keep = (p_hi - p_lo) <= batch
-    W_rows, kept = [], None
+    n_local = max(p_hi - p_lo, 1)
+    budget = SLAB_BUDGET_BYTES
+    if n_local * per_slab > budget:
+        budget = max(budget, int(0.8 * _free_device_bytes(dev)))
+    if n_local * per_slab <= budget:
+        batch = n_local
+    else:
+        batch = max(1, min(n_local, min(SLAB_BLOCK_BYTES, budget // 2) // max(per_slab, 1)))
+    W_rows, kept, kept_bytes = [], {}, 0
     for b0 in range(p_lo, p_hi, batch):
         b1 = min(b0 + batch, p_hi)
         dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps)
         W_rows.append(_interaction_rows(dE, swork, off, None))
-        if keep:
-            kept = dE
-        else:
-            del dE
+        # keep this block if it and one more working block still fit
+        if want_E and diffuse and kept_bytes + (b1 - b0) * per_slab + (batch * per_slab if b1 < p_hi else 0) <= budget:
+            kept[b0] = dE
+            kept_bytes += (b1 - b0) * per_slab
+        del dE
     if len(W_rows) == 1:
         W_local = W_rows[0]
     else:
@@ -698,17 +711,24 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
         # visit order; here the signed slabs are summed in fp64 and rounded to fp32 once, which is closer to the
         # exact sum and does not depend on the visit order or on how the patches are split over GPUs.
         Es = torch.empty((N, 3), dtype=torch.float64, device=dev)
-        if keep and kept is not None:
-            _combine_signed(kept, sigma, p_lo, Es, False)
-        else:
-            Es.zero_()
-            for b0 in range(p_lo, p_hi, batch):
-                b1 = min(b0 + batch, p_hi)
+        first = True
+        for b0 in range(p_lo, p_hi, batch):
+            b1 = min(b0 + batch, p_hi)
+            dE = kept.pop(b0, None)
+            if dE is None:
                 dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps)
-                _combine_signed(dE, sigma, b0, Es, True)
-                del dE
+            _combine_signed(dE, sigma, b0, Es, not first)
+            first = False
+            del dE
+        if first:
+            Es.zero_()
         E64 = Es
     return _Batched(order, sigma, chosen, E64, perm, swork, point_patch)
+
+
+def _free_device_bytes(dev) -> int:
+    """Bytes a new tensor could take: what the driver reports free plus what torch's allocator holds unused."""
+    return int(torch.cuda.mem_get_info(dev)[0]) + int(torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev))
 
 
 def _balanced_blocks(sizes: np.ndarray, world: int) -> np.ndarray:

@@ -359,6 +359,37 @@ def test_G6_patch_propagation(dev, tag, mode, monkeypatch):
     assert torch.equal(out[:, :3], cloud[:, :3])
 
 
+@pytest.mark.parametrize("tag", ["pf_d_w", "sc_d_nw", "pf_n_nw"])
+def test_G6_slabs_larger_than_the_memory_budget(dev, tag, monkeypatch):
+    """The batched driver when the [P, N, 3] slabs do not fit the device budget: blocks of patches, as many blocks
+    kept as fit, the others evaluated a second time for the diffuse combine - same trace and signs as the reference
+    (here: 72 fandisk patches in blocks of 12 with room for two blocks at a time)."""
+    g = load_golden("G6_patch_propagation")
+    cloud, patches, allp, diffuse, w = _patch_case(g, tag)
+    per_slab = cloud.shape[0] * 12
+    monkeypatch.setattr(fu, "PATCH_MODE", "batched")
+    monkeypatch.setattr(fu, "SLAB_BUDGET_BYTES", 20 * per_slab)
+    monkeypatch.setattr(fu, "_free_device_bytes", lambda dev: int(24.5 * per_slab / 0.8))     # budget 24 slabs: blocks of 12
+    calls = []
+    real = fu._patch_slabs
+    monkeypatch.setattr(fu, "_patch_slabs", lambda *a, **k: (calls.append((a[4], a[5])), real(*a, **k))[1])
+    pts = cloud.clone().to(dev)
+    allp_dev = [p.to(dev) for p in allp]
+    filt = [(i, allp_dev[i]) for i, _ in patches]
+    fu.strongest_field_propagation(pts, filt, allp_dev, diffuse=diffuse, weights=None if w is None else w.to(dev))
+    first_pass = [(b, min(b + 12, 72)) for b in range(0, 72, 12)]
+    if diffuse:                          # the first block and the last (no working block after it) were kept
+        assert calls == first_pass + first_pass[1:-1]
+    else:
+        assert calls == first_pass
+    tr = fu.last_trace("patches")
+    assert np.array_equal(tr["order"], g[f"order_{tag}"])
+    assert np.array_equal((tr["sigma"] < 0)[tr["order"]], g[f"flipped_{tag}"])
+    out = pts.cpu()
+    assert np.array_equal(((out[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g[f"sign_{tag}"])
+    assert np.abs(out[:, 3:].numpy() - g[f"normals_{tag}"]).max() < 1e-6
+
+
 @pytest.mark.parametrize("tag", ["pf_d_nw", "sc_n_w"])
 def test_G6_cpu_tensor_input_default_start(dev, tag):
     """CPU tensors in (like the reference's CPU run): staged to the device, same start patch, trace and signs."""
