@@ -14,7 +14,7 @@ Reference behaviour each function reproduces (file:line under the reference tree
 """
 import ctypes
 import time
-from typing import List, Tuple
+from typing import List
 
 import numpy as np
 import torch
