@@ -214,6 +214,129 @@ __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restri
     }
 }
 
+// ---- the same loop for more patches than one wavefront holds: ONE workgroup of 1024 threads, thread t owns patches
+// t, t + 1024, ... (EPT per thread); one barrier per step.  Every wave reduces its candidates as above, carrying the
+// signed interaction along, and leaves {|I|, j, I} in LDS (two sets by step parity: a set is rewritten only after
+// the barrier that follows its last read); every thread then folds the 16 records in wave order, so the first
+// maximum in patch order wins exactly as in the one-wavefront kernel.
+constexpr int kGreedyBlock = 1024;
+__device__ __forceinline__ void take_better3(double& bv, int& bj, double& sv, double ov, int oj, double osv) {
+    if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; sv = osv; }
+}
+// the same inside one 16-lane row only (the four DPP rounds)
+__device__ __forceinline__ void row_argmax3(double& bv, int& bj, double& sv) {
+    take_better3(bv, bj, sv, dpp_f64<0xB1>(bv), dpp_i32<0xB1>(bj), dpp_f64<0xB1>(sv));
+    take_better3(bv, bj, sv, dpp_f64<0x4E>(bv), dpp_i32<0x4E>(bj), dpp_f64<0x4E>(sv));
+    take_better3(bv, bj, sv, dpp_f64<0x141>(bv), dpp_i32<0x141>(bj), dpp_f64<0x141>(sv));
+    take_better3(bv, bj, sv, dpp_f64<0x140>(bv), dpp_i32<0x140>(bj), dpp_f64<0x140>(sv));
+}
+__device__ __forceinline__ double readfirstlane_f64(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b & 0xffffffffull));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void wave_argmax3(double& bv, int& bj, double& sv) {
+    take_better3(bv, bj, sv, dpp_f64<0xB1>(bv), dpp_i32<0xB1>(bj), dpp_f64<0xB1>(sv));
+    take_better3(bv, bj, sv, dpp_f64<0x4E>(bv), dpp_i32<0x4E>(bj), dpp_f64<0x4E>(sv));
+    take_better3(bv, bj, sv, dpp_f64<0x141>(bv), dpp_i32<0x141>(bj), dpp_f64<0x141>(sv));
+    take_better3(bv, bj, sv, dpp_f64<0x140>(bv), dpp_i32<0x140>(bj), dpp_f64<0x140>(sv));
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1)
+        take_better3(bv, bj, sv, __shfl_xor(bv, off, 64), __shfl_xor(bj, off, 64), __shfl_xor(sv, off, 64));
+}
+
+// The trace (order, chosen) goes through a two-block LDS ring of 64 steps that the LAST wave copies out every 64
+// steps: a global store inside the loop sits in front of the next row's loads in the storing wave's vmcnt queue and
+// costs a store round trip per step (3.0 against 1.3 us per step measured).
+template <int EPT>
+__global__ __launch_bounds__(kGreedyBlock) void patch_greedy_block_kernel(const double* __restrict__ W, int P,
+                                                                          const int64_t* __restrict__ start_ptr,
+                                                                          int64_t* __restrict__ order,
+                                                                          double* __restrict__ sigma,
+                                                                          double* __restrict__ chosen) {
+    constexpr int kWaves = kGreedyBlock / 64;
+    __shared__ double best_v[2][kWaves], best_s[2][kWaves];
+    __shared__ int best_j[2][kWaves];
+    __shared__ int order_r[2][64];
+    __shared__ double chosen_r[2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double inter[EPT];
+    unsigned visited = 0, negative = 0;                   // bit e <-> patch e*1024 + tid
+    int cur = (int)start_ptr[0];
+    if (cur < 0 || cur >= P) cur = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        inter[e] = 0.0;
+        if (e * kGreedyBlock + tid >= P) visited |= 1u << e;
+    }
+    double s = 1.0;                                       // the start patch is not flipped
+    int step = 0;
+    for (; step < P; ++step) {
+        if (tid == 0) order_r[(step >> 6) & 1][step & 63] = cur;
+        if ((cur & (kGreedyBlock - 1)) == tid) {
+            visited |= 1u << (cur / kGreedyBlock);
+            if (s < 0.0) negative |= 1u << (cur / kGreedyBlock);
+        }
+        const double* row = W + (int64_t)cur * P;
+        double r[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {                   // unconditional (clamped) loads, all in flight at once
+            const int j = e * kGreedyBlock + tid;
+            r[e] = row[j < P ? j : P - 1];
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (e * kGreedyBlock + tid < P) inter[e] += s * r[e];
+        if (step + 1 == P) break;
+        double bv = -1.0, sv = 0.0;
+        int bj = 0x7fffffff;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {                   // ascending j within the thread
+            double a = fabs(inter[e]);
+            if (a != a) a = __builtin_huge_val();         // a NaN counts as the maximum, as in torch.argmax
+            if (!((visited >> e) & 1u) && a > bv) { bv = a; bj = e * kGreedyBlock + tid; sv = inter[e]; }
+        }
+        wave_argmax3(bv, bj, sv);
+        const int par = step & 1;
+        if (lane == 0) { best_v[par][wave] = bv; best_j[par][wave] = bj; best_s[par][wave] = sv; }
+        __syncthreads();
+        // every trace entry of the steps before this one is in LDS now: the last wave copies a finished block out
+        if (wave == kWaves - 1 && step > 0 && (step & 63) == 0) {
+            const int blk = (step >> 6) - 1;
+            order[blk * 64 + lane] = order_r[blk & 1][lane];
+            chosen[blk * 64 + lane] = chosen_r[blk & 1][lane];
+        }
+        // lanes 0..15 of every wave take one record each (3 LDS reads per wave - every thread folding all 16 records
+        // itself is 48 LDS reads per thread and made the step LDS-issue bound: 3.1 us), four DPP rounds inside that
+        // 16-lane row leave the block's winner in lane 0, read out with v_readfirstlane
+        bv = (lane < kWaves) ? best_v[par][lane & (kWaves - 1)] : -1.0;
+        bj = (lane < kWaves) ? best_j[par][lane & (kWaves - 1)] : 0x7fffffff;
+        sv = (lane < kWaves) ? best_s[par][lane & (kWaves - 1)] : 0.0;
+        row_argmax3(bv, bj, sv);
+        cur = __builtin_amdgcn_readfirstlane(bj);         // the same in every thread
+        sv = readfirstlane_f64(sv);
+        s = (sv < 0.0) ? -1.0 : 1.0;                      // `if interaction[max] < 0: flip`
+        if (tid == 0) chosen_r[(step >> 6) & 1][step & 63] = sv;
+    }
+    __syncthreads();
+    // the last block, and the one before it (its in-loop copy is triggered by a step of the last block that may not
+    // have come; both ring halves are still intact, so copying it again is harmless).  order: P entries, chosen: P - 1
+    if (wave == kWaves - 1) {
+        const int last = (P - 1) >> 6;
+        for (int blk = (last > 0 ? last - 1 : 0); blk <= last; ++blk) {
+            const int i = blk * 64 + lane;
+            if (i < P) order[i] = order_r[blk & 1][lane];
+            if (i < P - 1) chosen[i] = chosen_r[blk & 1][lane];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int j = e * kGreedyBlock + tid;
+        if (j < P) sigma[j] = ((negative >> e) & 1u) ? -1.0 : 1.0;
+    }
+}
+
 // ---- the patch-sorted working layout in ONE launch: swork[i] = pts[idx[i]], sorted_patch[i] = p for the rows
 // i in [off[p], off[p+1]) of every patch p (one workgroup per patch); replaces a repeat_interleave (three launches), a
 // row gather and their temporaries in the drivers' set-up
@@ -322,7 +445,7 @@ int dnp_patch_pca_f64(const double* pts, int64_t ld_pts, const int64_t* patch_of
     return DNP_OK;
 }
 
-int dnp_patch_greedy_max_patches(void) { return 64 * 64; }
+int dnp_patch_greedy_max_patches(void) { return kGreedyBlock * 16; }
 
 int dnp_patch_greedy(const double* W, int64_t P, const int64_t* start, int64_t* order, double* sigma,
                      double* chosen, void* stream) {
@@ -336,7 +459,17 @@ int dnp_patch_greedy(const double* W, int64_t P, const int64_t* start, int64_t* 
     const hipStream_t st = (hipStream_t)stream;
 #define DNP_LAUNCH_PG(E) \
     hipLaunchKernelGGL((patch_greedy_kernel<E>), dim3(1), dim3(64), 0, st, W, (int)P, start, order, sigma, chosen)
-    if (P <= 64 * 4) DNP_LAUNCH_PG(4);
+    // one wavefront up to 2048 patches (0.8 us per step at 256, 2.25 at 2048, 4.3 at 4096: 64 row loads per lane),
+    // the one-workgroup kernel above (2.4-2.5 us per step up to 4096, 2.9 at 8192, 4.6 at 16384; tools/gpu_pg_time.py)
+#ifndef DNP_PG_BLOCK_FROM        // A/B builds move the crossover
+#define DNP_PG_BLOCK_FROM (64 * 32)
+#endif
+    if (P > DNP_PG_BLOCK_FROM) {
+        if (P <= kGreedyBlock * 8)
+            hipLaunchKernelGGL((patch_greedy_block_kernel<8>), dim3(1), dim3(kGreedyBlock), 0, st, W, (int)P, start, order, sigma, chosen);
+        else
+            hipLaunchKernelGGL((patch_greedy_block_kernel<16>), dim3(1), dim3(kGreedyBlock), 0, st, W, (int)P, start, order, sigma, chosen);
+    } else if (P <= 64 * 4) DNP_LAUNCH_PG(4);
     else if (P <= 64 * 8) DNP_LAUNCH_PG(8);
     else if (P <= 64 * 16) DNP_LAUNCH_PG(16);
     else if (P <= 64 * 32) DNP_LAUNCH_PG(32);

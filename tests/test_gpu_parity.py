@@ -433,7 +433,8 @@ def test_start_patch_rule_matches_the_reference_curvatures(dev):
 
 def test_patch_greedy_kernel_equals_the_host_loop(dev):
     """dnp_patch_greedy against greedy_order_from_interactions on the real W of G6 and on random matrices of
-    every size class (<= 256, 512, 1024, 2048, 4096 patches), ties included."""
+    every size class (<= 256, 512, 1024, 2048, 4096 patches: one wavefront; 4097..8192 and ..16384: the one-workgroup
+    kernel), ties included."""
     rng = np.random.default_rng(3)
     mats = []
     g = load_golden("G6_patch_propagation")
@@ -442,10 +443,12 @@ def test_patch_greedy_kernel_equals_the_host_loop(dev):
     off, idx, sizes = util.patch_csr(allp, dev)
     dE = fu._patch_slabs(pts, off, idx, fu._point_patch_ids(idx, sizes, pts.shape[0]), 0, 72, 1e-5)
     mats.append((fu._interaction_rows(dE, pts, off, idx).cpu().numpy(), 42))
-    for P, start in ((1, 0), (2, 1), (65, 64), (300, 7), (700, 699), (1500, 3), (2500, 11)):
+    for P, start in ((1, 0), (2, 1), (65, 64), (300, 7), (700, 699), (1500, 3), (2500, 11), (4100, 4099), (9001, 17)):
         mats.append((rng.standard_normal((P, P)) * np.exp(rng.standard_normal((P, 1)) * 3), start))
     tie = np.round(rng.standard_normal((130, 130)) * 2)              # many exact ties: first maximum must win
     mats.append((tie, 5))
+    mats.append((np.round(rng.standard_normal((4500, 4500)) * 2), 77))   # the same through the one-workgroup kernel
+    assert _lib.require_device().dnp_patch_greedy_max_patches() == 16384
     for W, start in mats:
         o_ref, s_ref, c_ref = fu.greedy_order_from_interactions(W, start)
         o, sg, c = fu._greedy_on_device(torch.from_numpy(W).to(dev), torch.tensor([start], device=dev))
