@@ -337,8 +337,6 @@ def test_G6_patch_propagation(dev, tag, mode, monkeypatch):
     chosen interactions and final signs of the reference."""
     g = load_golden("G6_patch_propagation")
     cloud, patches, allp, diffuse, w = _patch_case(g, tag)
-    if mode == "sequential" and tag not in ("pf_d_w", "sc_n_nw"):
-        pytest.skip("sequential form is covered on two representative cases")
     monkeypatch.setattr(fu, "PATCH_MODE", mode)
     pts = cloud.clone().to(dev)
     allp_dev = [p.to(dev) for p in allp]
