@@ -54,6 +54,15 @@ constexpr int kBlock = 256;       // threads per workgroup (4 waves, one per SIM
 #define DNP_FLUSH 64
 #endif
 constexpr int kFlush = DNP_FLUSH;  // sources between two spills of the fp32 sums into the fp64 sums
+#ifndef DNP_FLUSH_SCALAR
+#define DNP_FLUSH_SCALAR 128
+#endif
+// the same for the scalar-unit kernel in PATCH mode (fp32 slabs): 128 (fp32 chains of 64 adds per set) measured 2.1 %
+// faster than 64 on the bench workload (4.283 against 4.376 ms, profiles/r02_ab_scalar_forms.txt) at 1.9e-8 instead of
+// 1.3e-8 median error of the summed slabs.  The generic entry points (fp64 partial slabs) keep kFlush: on random-dipole
+// clouds, where rows are cancellation residues, 128 raised the worst row from 5.5e-6 to 8.4e-6 of |E| (N = 40 000) -
+// inside 1e-5, but margin better kept.
+constexpr int kFlushScalar = DNP_FLUSH_SCALAR;
 #ifndef DNP_SETS
 #define DNP_SETS 2
 #endif
@@ -516,7 +525,8 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
 
     int64_t s = s_begin;                                    // wave-uniform
     while (s < s_end) {
-        const int64_t run_end = (s + kFlush < s_end) ? s + kFlush : s_end;
+        constexpr int kRun = (sizeof(PT) == 4) ? kFlushScalar : kFlush;
+        const int64_t run_end = (s + kRun < s_end) ? s + kRun : s_end;
         if constexpr (MODE == kField) {
             if (kFarPath && far_chunk) scalar_field_run<F, KT, V, true>(src, sidx, ld, s, run_end, tx, ty, tz, a.eps, acc);
             else scalar_field_run<F, KT, V, false>(src, sidx, ld, s, run_end, tx, ty, tz, a.eps, acc);
