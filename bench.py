@@ -152,7 +152,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # 10 untimed steps by default: the first ~8 launches after an idle period run up to 25 % slower while the clocks
+    # ramp (5.3, 5.1, 4.8, 4.7, 4.6, 4.4, 4.4, 4.3 ms, then 4.26 +- 0.03; profiles/r02_kernel_trace_durations.txt)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the other_configs legs (profiling runs: only the headline kernels in the trace)")

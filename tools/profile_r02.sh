@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline --headline-only"
+ARGS="--steps 40 --warmup 10 --no-cpu-baseline --headline-only"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o r02 -- python3 $R/bench.py $ARGS > $OUT/trace_stdout.txt 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o r02 -- python3 $R/bench.py $ARGS > $OUT/pmc_fetch_stdout.txt 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o r02 -- python3 $R/bench.py $ARGS > $OUT/pmc_write_stdout.txt 2>&1

@@ -39,7 +39,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
         for c, xs in v.items():
             allc[k][c] = sum(xs) / len(xs)
 
-lines = [f"# {rnd}: rocprofv3 summary of `python bench.py --steps 10 --warmup 2 --no-cpu-baseline --headline-only` (1x MI355X)", "",
+lines = [f"# {rnd}: rocprofv3 summary of `python bench.py --steps 40 --warmup 10 --no-cpu-baseline --headline-only` (1x MI355X)", "",
          "Per-dispatch averages. Kernel-trace stats and every PMC group come from separate runs "
          "(tools/profile_r02.sh).", ""]
 traffic = {}
