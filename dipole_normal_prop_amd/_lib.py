@@ -31,6 +31,9 @@ SIGNATURES = {
                                          _c_i64, _c_p, _c_sz, _c_p]),
     "dnp_patch_fields_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64,
                                             ctypes.c_float, _c_p, _c_p]),
+    "dnp_patch_boxes_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p]),
+    "dnp_patch_fields_boxed_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64,
+                                                  ctypes.c_float, _c_p, _c_p]),
     "dnp_interactions_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p]),
     "dnp_combine_fields_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, ctypes.c_int, _c_p]),
     "dnp_xie_pairs_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, ctypes.c_float, ctypes.c_int,

@@ -67,11 +67,58 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
 
 using namespace dnp;
 
+namespace dnp {
+// bounding boxes of the patches' points: boxes[p] = (min x, y, z, max x, y, z) - one workgroup per patch
+__global__ __launch_bounds__(256) void patch_box_kernel(const float* __restrict__ pts, int64_t ld,
+                                                        const int64_t* __restrict__ off,
+                                                        const int64_t* __restrict__ idx, float* __restrict__ boxes) {
+    __shared__ float red[4][6];
+    const int64_t p = blockIdx.x;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int64_t q = off[p] + threadIdx.x; q < off[p + 1]; q += 256) {
+        const float* r = pts + (idx ? idx[q] : q) * ld;
+        for (int c = 0; c < 3; ++c) { lo[c] = r[c] < lo[c] ? r[c] : lo[c]; hi[c] = r[c] > hi[c] ? r[c] : hi[c]; }
+    }
+    for (int c = 0; c < 3; ++c) { lo[c] = wave_min<float>(lo[c]); hi[c] = wave_max<float>(hi[c]); }
+    if ((threadIdx.x & 63) == 0)
+        for (int c = 0; c < 3; ++c) { red[threadIdx.x >> 6][c] = lo[c]; red[threadIdx.x >> 6][3 + c] = hi[c]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        float l = red[0][c], h = red[0][3 + c];
+        for (int w = 1; w < 4; ++w) { l = red[w][c] < l ? red[w][c] : l; h = red[w][3 + c] > h ? red[w][3 + c] : h; }
+        boxes[p * 6 + c] = l;
+        boxes[p * 6 + 3 + c] = h;
+    }
+}
+}  // namespace dnp
+
 extern "C" {
+
+int dnp_patch_boxes_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
+                        const int64_t* patch_idx, int64_t P, float* boxes, void* stream) {
+    clear_error();
+    DNP_REQUIRE(N >= 0 && P >= 0, "negative size");
+    if (P == 0) return DNP_OK;
+    DNP_REQUIRE(pts && patch_off && boxes, "NULL pointer");               // patch_idx may be NULL (contiguous)
+    DNP_REQUIRE(ld_pts >= 3, "ld_pts=%lld < 3", (long long)ld_pts);
+    hipLaunchKernelGGL(patch_box_kernel, dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pts, ld_pts, patch_off,
+                       patch_idx, boxes);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
 
 int dnp_patch_fields_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
                          const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
                          int64_t p_begin, int64_t p_end, float eps, float* dE, void* stream) {
+    return dnp_patch_fields_boxed_f32(pts, N, ld_pts, patch_off, patch_idx, P, point_patch, nullptr, p_begin, p_end, eps,
+                                      dE, stream);
+}
+
+int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
+                               const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
+                               const float* patch_box, int64_t p_begin, int64_t p_end, float eps, float* dE,
+                               void* stream) {
     clear_error();
     DNP_REQUIRE(N >= 0 && P >= 0, "negative size");
     DNP_REQUIRE(0 <= p_begin && p_begin <= p_end && p_end <= P, "bad patch range [%lld,%lld) of %lld",
@@ -100,8 +147,13 @@ int dnp_patch_fields_f32(const float* pts, int64_t N, int64_t ld_pts, const int6
         if (!patch_idx && eps > 0.f && !DNP_FORCE_LDS) {
             // patch-sorted cloud (what the drivers pass): contiguous sources -> the scalar-unit kernel
             const dim3 sgrid((unsigned)ceil_div(N, (int64_t)kBlock * kPatchScalarKT), (unsigned)kn);
-            hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar>), sgrid,
-                               dim3(kBlock), 0, st, pa);
+            pa.chunk_box = patch_box;
+            if (patch_box && kPatchFar)
+                hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true>), sgrid,
+                                   dim3(kBlock), 0, st, pa);
+            else
+                hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar>), sgrid,
+                                   dim3(kBlock), 0, st, pa);
         } else {
             const dim3 grid((unsigned)t_tiles, (unsigned)kn);
             if (eps > 0.f)

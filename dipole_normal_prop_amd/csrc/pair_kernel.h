@@ -95,6 +95,7 @@ struct PairArgs {
     int out_scatter;         // row = tgt_idx[t]
     int accumulate;          // out += result
     int* nonfinite;          // [2] counters of inf / nan leaf components zeroed (direct epilogue), or nullptr
+    const F* chunk_box;      // [chunks][6] bounding boxes (lo xyz, hi xyz) of the chunks' sources, or nullptr: found by the workgroup
     F far_d2;                // scalar kernel, FAR: squared box distance beyond which the one-transcendental chain runs
     int32_t chunk_off[kMaxChunks + 1];  // by-value CSR offsets when chunk_off_dev == nullptr
 };
@@ -397,7 +398,9 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
 // against 4.36-4.42 ms for the form below in interleaved same-process A/B runs (profiles/r02_ab_scalar_forms.txt).
 // Re-run tools/gpu_ab_far.py after ANY edit here.
 // FAR: a wave whose target box is farther than sqrt(far_d2) from the box of the chunk's sources runs the whole chunk
-// through pair_field_far (one decision per wave and chunk; the chunk's box is found by the workgroup itself).
+// through pair_field_far (one decision per wave and chunk).  BOX: the chunks' boxes come from a.chunk_box (the patch
+// drivers compute them once per cloud, dnp_patch_boxes_f32); otherwise the workgroup finds its chunk's box itself
+// (a scan of the chunk, 36 ds_bpermute and a barrier per workgroup: 1.1 % of the bench launch).
 template <typename F, int KT, int V, bool FARCHAIN>
 __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, const int64_t* __restrict__ sidx, int64_t ld,
                                                int64_t& s, int64_t run_end, const F (&tx)[KT], const F (&ty)[KT],
@@ -439,7 +442,7 @@ __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, cons
         }
 }
 
-template <typename F, typename PT, int MODE, int KT, int V, bool FAR = false>
+template <typename F, typename PT, int MODE, int KT, int V, bool FAR = false, bool BOX = false>
 __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, PT> a) {
     using M = Math<F>;
     constexpr int NC = (MODE == kField) ? 3 : 1;
@@ -476,18 +479,21 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
 
     bool far_chunk = false;
     if (kFarPath && a.far_d2 > F(0)) {     // far_d2 <= 0: the launcher switched the far machinery off (small problems)
-        // box of the chunk's sources (workgroup-cooperative) and of this wave's targets
-        F lo[3] = {M::kHuge, M::kHuge, M::kHuge}, hi[3] = {-M::kHuge, -M::kHuge, -M::kHuge};
-        for (int64_t q = s_begin + tid; q < s_end; q += kBlock) {
-            const F* p = src + (sidx ? sidx[q] : q) * ld;
+        // box of the chunk's sources (given, or found by the workgroup) and of this wave's targets
+        constexpr bool given = BOX;          // a compile-time choice: a run-time branch here cost 19 VGPRs (occupancy 8 -> 6)
+        if constexpr (!given) {
+            F lo[3] = {M::kHuge, M::kHuge, M::kHuge}, hi[3] = {-M::kHuge, -M::kHuge, -M::kHuge};
+            for (int64_t q = s_begin + tid; q < s_end; q += kBlock) {
+                const F* p = src + (sidx ? sidx[q] : q) * ld;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { lo[c] = p[c] < lo[c] ? p[c] : lo[c]; hi[c] = p[c] > hi[c] ? p[c] : hi[c]; }
+                for (int c = 0; c < 3; ++c) { lo[c] = p[c] < lo[c] ? p[c] : lo[c]; hi[c] = p[c] > hi[c] ? p[c] : hi[c]; }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { lo[c] = wave_min<F>(lo[c]); hi[c] = wave_max<F>(hi[c]); }
+            if ((tid & 63) == 0)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { chunk_box[tid >> 6][c] = lo[c]; chunk_box[tid >> 6][3 + c] = hi[c]; }
         }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { lo[c] = wave_min<F>(lo[c]); hi[c] = wave_max<F>(hi[c]); }
-        if ((tid & 63) == 0)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { chunk_box[tid >> 6][c] = lo[c]; chunk_box[tid >> 6][3 + c] = hi[c]; }
         F tlo[3] = {M::kHuge, M::kHuge, M::kHuge}, thi[3] = {-M::kHuge, -M::kHuge, -M::kHuge};
 #pragma unroll
         for (int k = 0; k < KT; ++k)
@@ -498,21 +504,33 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
             }
 #pragma unroll
         for (int c = 0; c < 3; ++c) { tlo[c] = wave_min<F>(tlo[c]); thi[c] = wave_max<F>(thi[c]); }
-        __syncthreads();
         F d2box = F(0);
+        if constexpr (given) {
+            const F* b = a.chunk_box + (a.chunk_base + chunk) * 6;          // wave-uniform: scalar loads
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            F slo = chunk_box[0][c], shi = chunk_box[0][3 + c];
-#pragma unroll
-            for (int w = 1; w < kBlock / 64; ++w) {
-                slo = chunk_box[w][c] < slo ? chunk_box[w][c] : slo;
-                shi = chunk_box[w][3 + c] > shi ? chunk_box[w][3 + c] : shi;
+            for (int c = 0; c < 3; ++c) {
+                F gap = b[c] - thi[c];
+                const F gap2 = tlo[c] - b[3 + c];
+                gap = gap2 > gap ? gap2 : gap;
+                gap = gap > F(0) ? gap : F(0);
+                d2box = M::fma(gap, gap, d2box);
             }
-            F gap = slo - thi[c];
-            const F gap2 = tlo[c] - shi;
-            gap = gap2 > gap ? gap2 : gap;
-            gap = gap > F(0) ? gap : F(0);
-            d2box = M::fma(gap, gap, d2box);
+        } else {
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                F slo = chunk_box[0][c], shi = chunk_box[0][3 + c];
+#pragma unroll
+                for (int w = 1; w < kBlock / 64; ++w) {
+                    slo = chunk_box[w][c] < slo ? chunk_box[w][c] : slo;
+                    shi = chunk_box[w][3 + c] > shi ? chunk_box[w][3 + c] : shi;
+                }
+                F gap = slo - thi[c];
+                const F gap2 = tlo[c] - shi;
+                gap = gap2 > gap ? gap2 : gap;
+                gap = gap > F(0) ? gap : F(0);
+                d2box = M::fma(gap, gap, d2box);
+            }
         }
         far_chunk = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2)) != 0;
     }

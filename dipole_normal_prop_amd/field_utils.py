@@ -489,14 +489,27 @@ def _disjoint(idx: torch.Tensor, n: int) -> bool:
     return bool(torch.bincount(idx, minlength=n).max().item() <= 1)
 
 
-def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, eps: float) -> torch.Tensor:
+def _patch_boxes(work: torch.Tensor, off, idx) -> torch.Tensor:
+    """[P, 6] bounding boxes (min xyz, max xyz) of the patches' points (dnp_patch_boxes_f32): what the pair kernel's
+    far-field test compares a wavefront's targets with; computed once per cloud."""
+    lib = _lib.require_device()
+    P = off.shape[0] - 1
+    boxes = torch.empty((P, 6), dtype=torch.float32, device=work.device)
+    with _on_device(work.device):
+        rc = lib.dnp_patch_boxes_f32(_lib.ptr(work), work.shape[0], work.stride(0), _lib.ptr(off), _lib.ptr(idx), P,
+                                     _lib.ptr(boxes), _lib.current_stream())
+    _lib.check(rc)
+    return boxes
+
+
+def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, eps: float, boxes=None) -> torch.Tensor:
     lib = _lib.require_device()
     N = work.shape[0]
     dE = torch.empty((p1 - p0, N, 3), dtype=torch.float32, device=work.device)
     with _on_device(work.device):
-        rc = lib.dnp_patch_fields_f32(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
-                                      off.shape[0] - 1, _lib.ptr(point_patch), p0, p1, float(eps), _lib.ptr(dE),
-                                      _lib.current_stream())
+        rc = lib.dnp_patch_fields_boxed_f32(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
+                                            off.shape[0] - 1, _lib.ptr(point_patch), _lib.ptr(boxes), p0, p1, float(eps),
+                                            _lib.ptr(dE), _lib.current_stream())
     _lib.check(rc)
     return dE
 
@@ -679,6 +692,7 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
     # are evaluated by one launch and kept for the diffuse combine.  Beyond it the budget is raised to 80 % of what
     # the device has free (288 GB of HBM on an MI355X), the patches go through in blocks of at most SLAB_BLOCK_BYTES,
     # as many blocks as fit are kept, and only the others are evaluated a second time for the combine.
+    boxes = _patch_boxes(swork, off, None)               # for the far-field test of the pair kernel
     per_slab = N * 3 * 4
     n_local = max(p_hi - p_lo, 1)
     budget = SLAB_BUDGET_BYTES
@@ -691,7 +705,7 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
     W_rows, kept, kept_bytes = [], {}, 0
     for b0 in range(p_lo, p_hi, batch):
         b1 = min(b0 + batch, p_hi)
-        dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps)
+        dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes)
         W_rows.append(_interaction_rows(dE, swork, off, None))
         # keep this block if it and one more working block still fit
         if want_E and diffuse and kept_bytes + (b1 - b0) * per_slab + (batch * per_slab if b1 < p_hi else 0) <= budget:
@@ -716,7 +730,7 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
             b1 = min(b0 + batch, p_hi)
             dE = kept.pop(b0, None)
             if dE is None:
-                dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps)
+                dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes)
             _combine_signed(dE, sigma, b0, Es, not first)
             first = False
             del dE

@@ -23,7 +23,7 @@ class OracleStandIn:
     itself has no such switch."""
 
     @staticmethod
-    def slabs(work, off, idx, point_patch, b0, b1, eps, extent=None):
+    def slabs(work, off, idx, point_patch, b0, b1, eps, boxes=None):
         N = work.shape[0]
         idx = torch.arange(N) if idx is None else idx        # None: cloud sorted by patch
         dE = torch.zeros(b1 - b0, N, 3)
@@ -88,6 +88,7 @@ def _worker(rank, world, port, start, q):
         pts = cloud.clone()
         from dipole_normal_prop_amd import field_utils as fu
         fu._patch_slabs, fu._interaction_rows = OracleStandIn.slabs, OracleStandIn.interactions
+        fu._patch_boxes = lambda work, off, idx: None                            # only the device kernel reads them
         fu._greedy_on_device, fu._combine_signed = OracleStandIn.greedy, OracleStandIn.combine_signed
         fu._finish_batched = OracleStandIn.finish
         fu._prepare_work = lambda p, w: (p.detach().clone().float(), None)       # CPU working copy (no weights here)

@@ -262,6 +262,34 @@ def test_threads_call_concurrently(dev):
 
 
 # ---- batched per-patch fields, interaction matrix, combination ----------------------------------------
+def test_patch_boxes_and_boxed_fields(dev):
+    """dnp_patch_boxes_f32 against per-patch min / max, with and without the row gather; the slabs of the scalar-unit
+    kernel are bit-identical whether it is handed the boxes or finds them itself (boxunion, 100 000 points, the
+    reference's 369 patches, cloud sorted by patch)."""
+    g = load_golden("G15_boxunion_config3")
+    cloud = t(g["pc"]).to(dev)
+    off_np, idx_np = g["patch_off"].astype(np.int64), g["patch_idx"].astype(np.int64)
+    off, idx = t(off_np).to(dev), t(idx_np).to(dev)
+    P = len(off_np) - 1
+    boxes_gather = fu._patch_boxes(cloud, off, idx)
+    swork = cloud[idx].contiguous()
+    boxes = fu._patch_boxes(swork, off, None)
+    assert boxes.shape == (P, 6) and torch.equal(boxes, boxes_gather)
+    ref = torch.stack([torch.cat([swork[off_np[k]:off_np[k + 1], :3].min(0).values, swork[off_np[k]:off_np[k + 1], :3].max(0).values])
+                       for k in range(P)])
+    assert torch.equal(boxes, ref)
+    point_patch = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
+    plain = fu._patch_slabs(swork, off, None, point_patch, 100, 140, 1e-5)
+    boxed = fu._patch_slabs(swork, off, None, point_patch, 100, 140, 1e-5, boxes)
+    assert torch.equal(plain, boxed)
+    k = 117 - 100                                        # one slab against the fp64 oracle
+    others = (point_patch != 117).cpu()
+    src = swork[off_np[117]:off_np[118]].cpu().numpy()
+    rows = torch.nonzero(others).flatten()[::97]
+    ref64 = c_oracle.field_grad_f64(src, swork.cpu()[rows].numpy())
+    assert rel_rowwise(boxed[k].cpu()[rows], ref64) < TOL
+
+
 def test_patch_fields_interactions_and_combine(dev):
     g = load_golden("G6_patch_propagation")
     pts = t(g["pc_patchflip"]).to(dev)

@@ -26,8 +26,9 @@ NOFAR = os.path.join(ROOT, "tools", "bin", "libdnp_nofar.so")
 
 def bind(path):
     lib = ctypes.CDLL(path)
-    res, args = _lib.SIGNATURES["dnp_patch_fields_f32"]
-    lib.dnp_patch_fields_f32.restype, lib.dnp_patch_fields_f32.argtypes = res, args
+    for fn in ("dnp_patch_fields_f32", "dnp_patch_fields_boxed_f32", "dnp_patch_boxes_f32"):
+        res, args = _lib.SIGNATURES[fn]
+        getattr(lib, fn).restype, getattr(lib, fn).argtypes = res, args
     return lib
 
 
@@ -48,12 +49,20 @@ def main():
     pts = pc.to(dev)[idx].contiguous()
     N, P = pts.shape[0], len(sizes)
     point_patch = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
+    libs["nobox"] = libs["far"]
+    boxes = torch.empty((P, 6), dtype=torch.float32, device=dev)
+    assert libs["far"].dnp_patch_boxes_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(boxes),
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
     dE = {k: torch.empty((P, N, 3), dtype=torch.float32, device=dev) for k in libs}
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def launch(name):
-        rc = libs[name].dnp_patch_fields_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch), 0, P,
-                                             1e-5, _lib.ptr(dE[name]), stream)
+        if name == "nobox":          # the product library without the box table: every workgroup finds its patch's box
+            rc = libs[name].dnp_patch_fields_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch), 0, P,
+                                                 1e-5, _lib.ptr(dE[name]), stream)
+        else:
+            rc = libs[name].dnp_patch_fields_boxed_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch),
+                                                       _lib.ptr(boxes), 0, P, 1e-5, _lib.ptr(dE[name]), stream)
         assert rc == 0
 
     for name in libs:
