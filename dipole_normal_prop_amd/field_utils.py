@@ -924,8 +924,8 @@ def strongest_field_propagation_reps(input_pc, reps, diffuse=False, weights=None
         if known_disjoint and int(rep_sizes.sum()) + n_rest == N and isinstance(reps, util.RepLists) \
                 and reps.rests.disjoint:
             # representatives and rests partition the cloud (what the callers pass): no mask, no host round trip
-            rest = torch.sort(rest_csr[1]).values if n_rest else None
-            src_rows = torch.sort(all_reps).values
+            rest = rest_csr[1] if n_rest else None            # targets are independent rows: their order is free
+            src_rows = torch.sort(all_reps).values            # sources in point order, as the reference sums them
         else:
             is_rep = torch.zeros(N, dtype=torch.bool, device=dev)
             is_rep[all_reps] = True
