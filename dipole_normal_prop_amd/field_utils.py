@@ -902,28 +902,45 @@ def strongest_field_propagation_reps(input_pc, reps, diffuse=False, weights=None
         # (patch k = the contiguous row range of its representatives) and scatter back
         sub = work[all_reps].contiguous()
         sub_patches = util.PatchList(torch.arange(all_reps.shape[0], device=dev), rep_sizes)
-        E = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+        n_rest = int(rest_csr[2].sum())
+        # representatives and rests partition the cloud (what the callers pass): every point is listed exactly once
+        partition = known_disjoint and isinstance(reps, util.RepLists) and reps.rests.disjoint \
+            and int(rep_sizes.sum()) + n_rest == N
         if mode == "batched":
             st = _batched_patch_propagation(sub, sub_patches, start_t, diffuse)
             order, sigma, chosen = st.order, st.sigma, st.chosen
-            if st.Es is not None:
-                E[all_reps] = st.field().to(torch.float32)
             neg = sigma < 0
         else:
             order, sigma, chosen, E_sub = _sequential_patch_propagation(sub, list(sub_patches), int(start_t.item()),
                                                                         diffuse)
-            E[all_reps] = E_sub
             neg = torch.from_numpy(sigma < 0).to(dev)
-        _flip_by_listing(work, neg, all_reps, rep_pid)
-        _flip_by_listing(work, neg, rest_csr[1], rest_pid)
-        if diffuse:
-            _diffuse_sign_pass(work, E, rep_lists)
+        if mode == "batched" and partition:
+            # patch flips and the diffuse sign pass of the representatives in ONE launch (the patch drivers' fused
+            # tail on the sub-cloud, stored straight into the working cloud), then the rests' flips
+            lib = _lib.require_device()
+            to_point = all_reps[st.perm]                                   # sorted sub-cloud row -> point
+            with _on_device(dev):
+                rc = lib.dnp_patch_finish_f32(_lib.ptr(st.swork), st.swork.stride(0), st.swork.shape[0],
+                                              _lib.ptr(st.sorted_patch), _lib.ptr(st.sigma),
+                                              _lib.ptr(st.Es if diffuse else None), None, None, _lib.ptr(to_point),
+                                              _lib.ptr(work), work.stride(0), 0, _lib.current_stream())
+            _lib.check(rc)
+            _flip_by_listing(work, neg, rest_csr[1], rest_pid)
+        else:
+            E = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+            if mode == "batched":
+                if st.Es is not None:
+                    E[all_reps] = st.field().to(torch.float32)
+            else:
+                E[all_reps] = E_sub
+            _flip_by_listing(work, neg, all_reps, rep_pid)
+            _flip_by_listing(work, neg, rest_csr[1], rest_pid)
+            if diffuse:
+                _diffuse_sign_pass(work, E, rep_lists)
         # every non-representative point: sign of the field of all representatives
         # (field_grad(pts[oriented_pts_mask], pts[~oriented_pts_mask]): both sides in point order)
-        n_rest = int(rest_csr[2].sum())
-        if known_disjoint and int(rep_sizes.sum()) + n_rest == N and isinstance(reps, util.RepLists) \
-                and reps.rests.disjoint:
-            # representatives and rests partition the cloud (what the callers pass): no mask, no host round trip
+        if partition:
+            # no mask, no host round trip
             rest = rest_csr[1] if n_rest else None            # targets are independent rows: their order is free
             src_rows = torch.sort(all_reps).values            # sources in point order, as the reference sums them
         else:
