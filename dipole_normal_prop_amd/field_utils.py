@@ -942,7 +942,7 @@ def strongest_field_propagation_reps(input_pc, reps, diffuse=False, weights=None
         if partition:
             # no mask, no host round trip
             rest = rest_csr[1] if n_rest else None            # targets are independent rows: their order is free
-            src_rows = torch.sort(all_reps).values            # sources in point order, as the reference sums them
+            src_rows = reps.sorted_reps(dev)                  # sources in point order, as the reference sums them
         else:
             is_rep = torch.zeros(N, dtype=torch.bool, device=dev)
             is_rep[all_reps] = True

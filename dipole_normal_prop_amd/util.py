@@ -223,7 +223,15 @@ class RepLists(list):
 
     def __init__(self, reps: PatchList, rests: PatchList):
         self.reps, self.rests = reps, rests
+        self._sorted_reps = None
         super().__init__(zip(reps, rests))
+
+    def sorted_reps(self, dev) -> torch.Tensor:
+        """All representatives in point order (the order in which the reference's final field_grad sums them),
+        sorted once per object and device."""
+        if self._sorted_reps is None or self._sorted_reps.device != torch.device(dev):
+            self._sorted_reps = torch.sort(self.reps.flat.to(device=dev, dtype=torch.int64)).values
+        return self._sorted_reps
 
 
 def patch_csr(patches, dev):
