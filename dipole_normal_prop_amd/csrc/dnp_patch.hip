@@ -26,7 +26,9 @@ __global__ __launch_bounds__(256) void interactions_kernel(const float* __restri
                                                            const int64_t* __restrict__ patch_off,
                                                            const int64_t* __restrict__ patch_idx, int64_t P,
                                                            double* __restrict__ W) {
-    const int64_t j = blockIdx.x, k = blockIdx.y;
+    // newest slab first: the pair kernel wrote the slabs in patch order and the last ~256 MB of them are still in the
+    // memory-side cache - walking them oldest-first would evict exactly the lines about to be read
+    const int64_t j = blockIdx.x, k = (int64_t)gridDim.y - 1 - blockIdx.y;
     const int64_t lo = patch_off[j], hi = patch_off[j + 1];
     const float* slab = dE + k * N * 3;
     double s = 0.0;
