@@ -38,8 +38,10 @@
 // at 8 back to back and ~13 when mixed with FMAs, so the exact chain costs ~70 cycles per 64 pairs per SIMD and
 // the FP32 vector ALU is the roofline (DESIGN.md section 4 lists the alternatives that were measured).
 //
-// Accumulation: fp32 inside a run of kFlush = 64 sources, spread over kSets = 2 interleaved accumulator
-// sets (chains of 32 adds), fp64 across runs (one cvt+fma per run, ~1 % of the issue slots) - the
+// Accumulation: fp32 inside a run of kFlush = 32 sources (128 in the patch mode of the scalar kernel, see
+// kFlushScalar), spread over kSets = 2 interleaved accumulator sets (chains of 16 adds), fp64 across runs (one
+// cvt+fma per run, ~2 % of the issue slots; 64-source runs were 1.4 % faster and left the worst row of the
+// random-dipole cloud G11 at 7.3e-6 of |E| instead of 4.5e-6 - margin towards the 1e-5 bound comes first) - the
 // reference's own sum is a cascade sum (torch CPU); a plain fp32 chain over 10^5 terms would not
 // stay within 1e-5 of it, and with 128-long chains the accumulation error still dominated the
 // per-term rounding on cancellation-heavy rows (tools/gpu_accuracy.py).
@@ -51,7 +53,7 @@ namespace dnp {
 
 constexpr int kBlock = 256;       // threads per workgroup (4 waves, one per SIMD)
 #ifndef DNP_FLUSH
-#define DNP_FLUSH 64
+#define DNP_FLUSH 32
 #endif
 constexpr int kFlush = DNP_FLUSH;  // sources between two spills of the fp32 sums into the fp64 sums
 #ifndef DNP_FLUSH_SCALAR
@@ -59,9 +61,9 @@ constexpr int kFlush = DNP_FLUSH;  // sources between two spills of the fp32 sum
 #endif
 // the same for the scalar-unit kernel in PATCH mode (fp32 slabs): 128 (fp32 chains of 64 adds per set) measured 2.1 %
 // faster than 64 on the bench workload (4.283 against 4.376 ms, profiles/r02_ab_scalar_forms.txt) at 1.9e-8 instead of
-// 1.3e-8 median error of the summed slabs.  The generic entry points (fp64 partial slabs) keep kFlush: on random-dipole
-// clouds, where rows are cancellation residues, 128 raised the worst row from 5.5e-6 to 8.4e-6 of |E| (N = 40 000) -
-// inside 1e-5, but margin better kept.
+// 1.3e-8 median error of the summed slabs.  The generic entry points (fp64 partial slabs) keep the short kFlush: on
+// random-dipole clouds, where rows are cancellation residues, 128 raised the worst row from 5.5e-6 (at 64) to 8.4e-6
+// of |E| (N = 40 000) - inside 1e-5, but margin better kept.
 constexpr int kFlushScalar = DNP_FLUSH_SCALAR;
 #ifndef DNP_SETS
 #define DNP_SETS 2
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
             const int j1 = (j0 + kFlush < n_here) ? j0 + kFlush : n_here;   // multiples of kSets
             if (MODE == kField) {
                 // kSets interleaved accumulator sets: source j goes to set j % kSets, so an fp32 chain is
-                // kFlush / kSets = 32 adds long (no extra loop instructions, only registers)
+                // kFlush / kSets = 16 adds long (no extra loop instructions, only registers)
                 F A[kSets][KT][3], B[kSets][KT][3];
 #pragma unroll
                 for (int u = 0; u < kSets; ++u)
