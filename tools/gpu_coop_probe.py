@@ -1,5 +1,7 @@
+"""Runs the per-point propagation in one chosen form (argv[1] = coop | single) - the process rocprofv3 was wrapped around to
+find that hipLaunchCooperativeKernel makes the profiler crash at exit (the launch was replaced by an occupancy check)."""
 import sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from dipole_normal_prop_amd import field_utils as fu
 from tools.gpu_check import sphere
 which = sys.argv[1]

@@ -1,5 +1,6 @@
+"""field_grad at N = 30 000: per-call time synchronised and unsynchronised (the sweep's outlier there was a timing-loop artifact)."""
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from dipole_normal_prop_amd import field_utils as fu
 from tools.gpu_check import sphere
 dev = torch.device("cuda:0")

@@ -1,3 +1,4 @@
+"""cProfile of the Python side of the batched patch driver on the 100k sphere (where the host time of one propagation goes)."""
 import os, sys, time, cProfile, pstats
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

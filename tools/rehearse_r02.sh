@@ -1,3 +1,6 @@
+#!/bin/bash
+# BENCH_BACKEND=gloo rehearsal of bench.py --gpus 2 / 4 on one GPU, then one rank's share of an N-rank run (BENCH_FAKE_WORLD)
+# for N = 1, 2, 4, 8: the evidence under profiles/r02_bench_gloo_rehearsal.txt and profiles/r02_rank_share_timing.txt.
 set +e
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 OUT=gpurun_out/rehearsal.txt
