@@ -251,7 +251,13 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
     // against 95 us, 3000^2: 20 against 29 us); from ~5 10^8 pairs on the scalar kernel is level or ahead
     // (30 000^2: 473 against 496 us) and is the one that can take the far-field chain on sorted clouds
     // (profiles/r02_k1_planning.txt).
-    const bool scalar_kernel = (src_idx == nullptr) && !DNP_K1_FORCE_LDS && (double)S * (double)T >= 5e8;
+#ifndef DNP_K1_SCALAR_FROM   // pairs from which the scalar-unit kernel takes over / may use the far chain (A/B builds move them)
+#define DNP_K1_SCALAR_FROM 5e8
+#endif
+#ifndef DNP_K1_FAR_FROM
+#define DNP_K1_FAR_FROM 1e9
+#endif
+    const bool scalar_kernel = (src_idx == nullptr) && !DNP_K1_FORCE_LDS && (double)S * (double)T >= DNP_K1_SCALAR_FROM;
     const Plan plan = make_plan(S, T, max_pts, NC, sizeof(double), scalar_kernel);
     const size_t need = plan_workspace(plan, T, NC, sizeof(double));
     if (!workspace || workspace_bytes < need) {
@@ -275,7 +281,7 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
         pa.nonfinite = nonfinite;
         // the far-field chain only pays for spatially sorted clouds; its per-workgroup set-up (box scan + barrier) is
         // noise for big problems and a measurable 5-10 % for small ones (fandisk): off below 10^9 pairs
-        pa.far_d2 = (eps > F(0) && (double)S * (double)T >= 1e9) ? (F)pow((double)eps / kFarRatio, 2.0 / 3.0) : F(0);
+        pa.far_d2 = (eps > F(0) && (double)S * (double)T >= DNP_K1_FAR_FROM) ? (F)pow((double)eps / kFarRatio, 2.0 / 3.0) : F(0);
         for (int i = 0; i <= n_chunks; ++i) pa.chunk_off[i] = r.chunk_off[i];
         const dim3 grid((unsigned)t_tiles, (unsigned)n_chunks);
         // eps > 0 (what every caller of the reference passes): the short chain; otherwise the explicit one
