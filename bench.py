@@ -96,8 +96,15 @@ def other_configs(dev, fu, util, pts_sorted, patch_ranges):
     out = {}
 
     def timed(fn, reps):
-        fn()
-        torch.cuda.synchronize()
+        # untimed calls first: after the host-side preparation of a leg the clocks have dropped, and the first ~40 ms of
+        # GPU work run up to 25 % slower (profiles/r02_kernel_trace_durations.txt)
+        t_warm = time.perf_counter()
+        for _ in range(3):
+            fn()
+            torch.cuda.synchronize()
+        while time.perf_counter() - t_warm < 0.05:
+            fn()
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
             fn()

@@ -369,8 +369,8 @@ def reference_field(pc1, pc2):
         E = field_grad(pc1, pc2, recursive=True)
         if pc2.shape[1] == 3:
             length = E.norm(dim=-1)
-            nz = length != 0
-            E[nz, :] = E[nz, :] / length[nz, None]
+            # E[length != 0] /= length, without the boolean-mask gather (a host round trip): x / 1 == x exactly
+            E = E / torch.where(length != 0, length, torch.ones_like(length))[:, None]
             pc2 = torch.cat([pc2, E], dim=1)
         else:
             interactions = (E * pc2[:, 3:]).sum(dim=-1)
