@@ -1,5 +1,7 @@
+"""field_grad / reference_field at S = T = 100 000 on the patch-sorted sphere with 6-column, 3-column and jittered targets
+(BASELINE config 5): where the time of a reference_field call goes."""
 import os, sys, time, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import sphere_cloud, fibonacci_patches
 from dipole_normal_prop_amd import field_utils as fu, util
 dev = torch.device("cuda:0")
