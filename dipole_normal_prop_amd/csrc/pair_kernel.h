@@ -399,11 +399,14 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
 // very sensitive to how the loop is written: semantically identical variants of scalar_field_run (row gather ternary
 // removed; loads hoisted in front of the group; explicit next-group prefetch) measured 4.56-5.14 ms per 10^10 pairs
 // against 4.36-4.42 ms for the form below in interleaved same-process A/B runs (profiles/r02_ab_scalar_forms.txt).
-// Re-run tools/gpu_ab_far.py after ANY edit here.
+// Re-run tools/gpu_ab_far.py after ANY edit here.  (One edit that did pay, late in round 2: the 32-bit trip count below.)
 // FAR: a wave whose target box is farther than sqrt(far_d2) from the box of the chunk's sources runs the whole chunk
 // through pair_field_far (one decision per wave and chunk).  BOX: the chunks' boxes come from a.chunk_box (the patch
 // drivers compute them once per cloud, dnp_patch_boxes_f32); otherwise the workgroup finds its chunk's box itself
 // (a scan of the chunk, 36 ds_bpermute and a barrier per workgroup: 1.1 % of the bench launch).
+#ifndef DNP_LOOP32     // 1: 32-bit trip count for the group loop - with the 64-bit `s + kUnroll <= run_end` form the compare ran on
+#define DNP_LOOP32 1  // the VALU (no scalar 64-bit order compare on gfx950): 2 of 94 VALU instructions per group, 2.6 % of a launch
+#endif
 template <typename F, int KT, int V, bool FARCHAIN>
 __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, const int64_t* __restrict__ sidx, int64_t ld,
                                                int64_t& s, int64_t run_end, const F (&tx)[KT], const F (&ty)[KT],
@@ -428,10 +431,18 @@ __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, cons
                                  A[set][k][2], B[set][k][0], B[set][k][1], B[set][k][2]);
         }
     };
+#if DNP_LOOP32
+    const int n_groups = (int)((run_end - s) / kUnroll);            // <= 64: a 32-bit trip count keeps the compare scalar
+    for (int g = 0; g < n_groups; ++g, s += kUnroll) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) one(sidx ? sidx[s + u] : s + u, u % kSets);
+    }
+#else
     for (; s + kUnroll <= run_end; s += kUnroll) {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) one(sidx ? sidx[s + u] : s + u, u % kSets);
     }
+#endif
     for (; s < run_end; ++s) one(sidx ? sidx[s] : s, 0);
 #pragma unroll
     for (int k = 0; k < KT; ++k)
