@@ -200,6 +200,33 @@ __device__ __forceinline__ void pair_field_far(F sx, F sy, F sz, F px, F py, F p
     bz = M::fma(w, pz, bz);
 }
 
+// Second tier (e = eps / |r|^3 < kFar2Ratio = 2.4e-4): the e^2 term is below one fp32 ulp too - w = u3 (1 - e), one
+// instruction less (22 full-rate + 1 transcendental).
+#ifndef DNP_FAR2      // 1: second tier on (4.187 -> 4.096 ms per launch on the bench workload, summed-slab accuracy unchanged)
+#define DNP_FAR2 1
+#endif
+constexpr double kFar2Ratio = 2.4e-4;
+template <typename F>
+__device__ __forceinline__ void pair_field_far2(F sx, F sy, F sz, F px, F py, F pz, F tx, F ty, F tz, F eps,
+                                                F& ax, F& ay, F& az, F& bx, F& by, F& bz) {
+    using M = Math<F>;
+    const F rx = sx - tx, ry = sy - ty, rz = sz - tz;
+    const F d2 = M::fma(rz, rz, M::fma(ry, ry, rx * rx));
+    const F pr = M::fma(pz, rz, M::fma(py, ry, px * rx));
+    const F u = M::rsq(d2);
+    const F u2 = u * u;
+    const F u3 = u2 * u;
+    const F e = eps * u3;
+    const F w = M::fma(-e, u3, u3);
+    const F a = pr * (w * u2);
+    ax = M::fma(a, rx, ax);
+    ay = M::fma(a, ry, ay);
+    az = M::fma(a, rz, az);
+    bx = M::fma(w, px, bx);
+    by = M::fma(w, py, by);
+    bz = M::fma(w, pz, bz);
+}
+
 template <typename F>
 __device__ __forceinline__ F wave_min(F v) {
 #pragma unroll
@@ -407,7 +434,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
 #ifndef DNP_LOOP32     // 1: 32-bit trip count for the group loop - with the 64-bit `s + kUnroll <= run_end` form the compare ran on
 #define DNP_LOOP32 1  // the VALU (no scalar 64-bit order compare on gfx950): 2 of 94 VALU instructions per group, 2.6 % of a launch
 #endif
-template <typename F, int KT, int V, bool FARCHAIN>
+template <typename F, int KT, int V, int FARCHAIN>
 __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, const int64_t* __restrict__ sidx, int64_t ld,
                                                int64_t& s, int64_t run_end, const F (&tx)[KT], const F (&ty)[KT],
                                                const F (&tz)[KT], F eps, double (&acc)[KT][3]) {
@@ -423,7 +450,10 @@ __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, cons
         const F sx = p[0], sy = p[1], sz = p[2], px = p[3], py = p[4], pz = p[5];
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-            if (FARCHAIN)
+            if (FARCHAIN == 2)
+                pair_field_far2<F>(sx, sy, sz, px, py, pz, tx[k], ty[k], tz[k], eps, A[set][k][0], A[set][k][1],
+                                   A[set][k][2], B[set][k][0], B[set][k][1], B[set][k][2]);
+            else if (FARCHAIN == 1)
                 pair_field_far<F>(sx, sy, sz, px, py, pz, tx[k], ty[k], tz[k], eps, A[set][k][0], A[set][k][1],
                                   A[set][k][2], B[set][k][0], B[set][k][1], B[set][k][2]);
             else
@@ -491,7 +521,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
     const int64_t* __restrict__ sidx = a.src_idx;
     const int64_t ld = a.ld_src;
 
-    bool far_chunk = false;
+    int far_chunk = 0;
     if (kFarPath && a.far_d2 > F(0)) {     // far_d2 <= 0: the launcher switched the far machinery off (small problems)
         // box of the chunk's sources (given, or found by the workgroup) and of this wave's targets
         constexpr bool given = BOX;          // a compile-time choice: a run-time branch here cost 19 VGPRs (occupancy 8 -> 6)
@@ -546,7 +576,12 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
                 d2box = M::fma(gap, gap, d2box);
             }
         }
-        far_chunk = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2)) != 0;
+#if DNP_FAR2
+        constexpr F kFar2Scale = (F)6.5242;     // (kFarRatio / kFar2Ratio)^(2/3) = (4e-3 / 2.4e-4)^(2/3)
+        far_chunk = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2) + (int)(d2box > a.far_d2 * kFar2Scale));
+#else
+        far_chunk = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2));
+#endif
     }
 
     double acc[KT][NC];
@@ -560,8 +595,12 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
         constexpr int kRun = (sizeof(PT) == 4) ? kFlushScalar : kFlush;
         const int64_t run_end = (s + kRun < s_end) ? s + kRun : s_end;
         if constexpr (MODE == kField) {
-            if (kFarPath && far_chunk) scalar_field_run<F, KT, V, true>(src, sidx, ld, s, run_end, tx, ty, tz, a.eps, acc);
-            else scalar_field_run<F, KT, V, false>(src, sidx, ld, s, run_end, tx, ty, tz, a.eps, acc);
+#if DNP_FAR2
+            if (kFarPath && far_chunk == 2) scalar_field_run<F, KT, V, 2>(src, sidx, ld, s, run_end, tx, ty, tz, a.eps, acc);
+            else
+#endif
+            if (kFarPath && far_chunk) scalar_field_run<F, KT, V, 1>(src, sidx, ld, s, run_end, tx, ty, tz, a.eps, acc);
+            else scalar_field_run<F, KT, V, 0>(src, sidx, ld, s, run_end, tx, ty, tz, a.eps, acc);
         } else {
             F P[kSets][KT];
 #pragma unroll
