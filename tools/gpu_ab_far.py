@@ -45,6 +45,17 @@ def main():
     dev = torch.device("cuda:0")
     pc = sphere_cloud()
     patches = fibonacci_patches(pc)
+    if os.environ.get("AB_MORTON"):           # experiment: points of a patch in Morton order (compact waves of targets)
+        def morton(x):
+            q = ((x - x.min(0).values) / (x.max(0).values - x.min(0).values + 1e-12) * 1023).long().clamp(0, 1023)
+            def spread(v):
+                v = (v | (v << 16)) & 0x030000FF
+                v = (v | (v << 8)) & 0x0300F00F
+                v = (v | (v << 4)) & 0x030C30C3
+                v = (v | (v << 2)) & 0x09249249
+                return v
+            return spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        patches = [p[torch.argsort(morton(pc[p, :3]))] for p in patches]
     off, idx, sizes = util.patch_csr(patches, dev)
     pts = pc.to(dev)[idx].contiguous()
     N, P = pts.shape[0], len(sizes)
