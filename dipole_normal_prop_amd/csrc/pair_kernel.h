@@ -577,7 +577,8 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
             }
         }
 #if DNP_FAR2
-        constexpr F kFar2Scale = (F)6.5242;     // (kFarRatio / kFar2Ratio)^(2/3) = (4e-3 / 2.4e-4)^(2/3)
+        static_assert(kFarRatio == 4e-3 && kFar2Ratio == 2.4e-4, "kFar2Scale below is (kFarRatio / kFar2Ratio)^(2/3)");
+        constexpr F kFar2Scale = (F)6.5242;     // (4e-3 / 2.4e-4)^(2/3)
         far_chunk = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2) + (int)(d2box > a.far_d2 * kFar2Scale));
 #else
         far_chunk = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2));
