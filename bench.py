@@ -33,31 +33,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_POINTS = 100_000
-N_PATCHES = 256
+from tools.workloads import N_PATCHES, N_POINTS, fibonacci_patches, headline_workload, sphere_cloud  # noqa: E402,F401
+
 FLOP_PER_PAIR = 33            # 3 sub, 5 r.r, 5 p.r, sqrt, 2 fma (4), rcp, 2 mul, 12 accumulate
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md (= the dense f32 MFMA peak)
 HBM_PEAK_GBS = 8000.0
-
-
-def sphere_cloud(n=N_POINTS, seed=1234):
-    """randn normalised, outward normals, unit-box Transform."""
-    g = torch.Generator().manual_seed(seed)
-    x = torch.randn(n, 3, generator=g)
-    nrm = x / x.norm(dim=-1, keepdim=True)
-    pc = torch.cat([nrm, nrm], dim=1)
-    pc[:, :3] -= pc[:, :3].mean(dim=0)[None, :]
-    pc[:, :3] = pc[:, :3] / (pc[:, :3].max(dim=0)[0] - pc[:, :3].min(dim=0)[0]).max()
-    return pc
-
-
-def fibonacci_patches(pc, P=N_PATCHES):
-    k = torch.arange(P, dtype=torch.float64) + 0.5
-    phi = torch.acos(1 - 2 * k / P)
-    theta = np.pi * (1 + 5 ** 0.5) * k
-    c = torch.stack([torch.cos(theta) * torch.sin(phi), torch.sin(theta) * torch.sin(phi), torch.cos(phi)], 1).float()
-    lab = (pc[:, 3:6] @ c.T).argmax(dim=1)
-    return [torch.nonzero(lab == j).flatten() for j in range(P)]
 
 
 def cpu_baseline(pc_cpu, seconds_target=15.0):
@@ -187,15 +167,10 @@ def main():
     from dipole_normal_prop_amd import field_utils as fu
     from dipole_normal_prop_amd import parallel, util
 
-    pc_cpu = sphere_cloud()
-    patches = fibonacci_patches(pc_cpu)
+    # whole patches flipped at random (seed 0): the propagation has 256 sign decisions to get right, checked below
+    pc_cpu, patches, scramble = headline_workload()
     sizes = np.array([len(p) for p in patches])
     pairs_total = float((sizes * (N_POINTS - sizes)).sum())
-    # whole patches flipped at random (seed 0): the propagation has 256 sign decisions to get right, checked below
-    scramble = (torch.rand(N_PATCHES, generator=torch.Generator().manual_seed(0)) < 0.5).numpy()
-    for k, p in enumerate(patches):
-        if scramble[k]:
-            pc_cpu[p, 3:] *= -1
     # layout: the cloud sorted by patch (what the drivers do, field_utils._batched_patch_propagation), so a
     # patch is a contiguous row range and every slab / interaction access is coalesced
     off, idx, _ = util.patch_csr(patches, dev)
@@ -211,22 +186,36 @@ def main():
         p_lo, p_hi = int(fb[0]), int(fb[1])
     my_pairs = float((sizes[p_lo:p_hi] * (N_POINTS - sizes[p_lo:p_hi])).sum())
 
-    def step():
+    # HIP events on the stream the kernels are launched on (torch's current stream = what _lib.current_stream() hands
+    # to the C ABI), recorded INSIDE the timed steps: the pair kernel's duration, the interaction kernel's and the
+    # all-gather's come from the same launches, buffers and clocks as ms_per_step
+    def step(marks=None):
+        if marks is not None:
+            marks[0].record()
         dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes)
+        if marks is not None:
+            marks[1].record()
         W = fu._interaction_rows(dE, pts, off, idx)
-        return parallel.gather_rows(W, bounds)
+        if marks is not None:
+            marks[2].record()
+        W = parallel.gather_rows(W, bounds)
+        if marks is not None:
+            marks[3].record()
+        return W
 
     def fence():
         if world > 1:
-            dist.barrier()
+            # device_ids: under nccl a barrier without it guesses the device from the rank
+            dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         W = step()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        W = step()
+    for i in range(args.steps):
+        W = step(ev[i])
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -237,33 +226,46 @@ def main():
     # developer aid BENCH_FAKE_WORLD: only one rank's share was computed, so only that share is credited
     value = (my_pairs if (fake > 1 and world == 1) else pairs_total) * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel: HIP events around the pair-kernel launch alone ------------------
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b in ev:
-        a.record()
-        dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes)
-        b.record()
-    torch.cuda.synchronize()
-    k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    # ---- roofline of the dominant kernel, from the events of the timed steps ---------------------------------
+    k_all = np.array([m[0].elapsed_time(m[1]) for m in ev])
+    k3_all = np.array([m[1].elapsed_time(m[2]) for m in ev])
+    ag_all = np.array([m[2].elapsed_time(m[3]) for m in ev])
+    k_ms, k_med, k_min = float(k_all.mean()), float(np.median(k_all)), float(k_all.min())
+    # the launch is part of the step: its mean over the timed steps cannot exceed the mean step of the slowest rank
+    assert k_ms <= ms_per_step * 1.0005, f"pair-kernel launch {k_ms:.4f} ms > step {ms_per_step:.4f} ms: timing is inconsistent"
     # flops: the kernel also evaluates (and zeroes) the pairs inside each source patch
     launch_pairs = float((sizes[p_lo:p_hi] * N_POINTS).sum())
     tflops = launch_pairs * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
     algo_bytes = 36.0 * N_POINTS + 12.0 * N_POINTS * (p_hi - p_lo)   # cloud read once + [K,N,3] slab written once
     roofline = {"bound": "valu", "achieved": tflops,
                 "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VALU_PEAK_TFLOPS,
-                "traffic": None, "launch_ms": k_ms, "flop_per_pair": FLOP_PER_PAIR,
-                "pairs_per_launch": launch_pairs,
-                "timed": "HIP events around dnp_patch_fields_f32 (one pair_kernel launch) on torch's current stream",
+                "traffic": None, "launch_ms": k_ms, "launch_ms_median": k_med, "launch_ms_min": k_min,
+                "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": launch_pairs,
+                "timed": f"HIP events around dnp_patch_fields_boxed_f32 (one pair_kernel_scalar launch) on torch's current "
+                         f"stream, recorded inside the {args.steps} timed steps; achieved = 33 flop x pairs_per_launch / "
+                         f"mean launch_ms",
                 "note": "FP32 vector ALU binds (no MFMA on this path); peak equals the dense f32 MFMA peak; 33 flop "
                         "per pair is the exact chain's count - pairs that take the far-field chain execute 45"}
     hbm = {"bound": "hbm", "achieved": algo_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
            "traffic": None}
+    step_parts = {"pair_kernel_ms": k_ms, "interactions_kernel_ms": float(k3_all.mean()),
+                  "gather_rows_ms": float(ag_all.mean())}
+    per_rank = None
+    if world > 1:
+        # so that a scaling run explains itself: every rank's kernel time and its wait in the all-gather
+        mine = torch.tensor([k_ms, k_min, float(k3_all.mean()), float(ag_all.mean()), float(ag_all.min()), my_pairs],
+                            dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "pair_kernel_ms": float(t[0]), "pair_kernel_ms_min": float(t[1]),
+                     "interactions_kernel_ms": float(t[2]), "gather_rows_ms": float(t[3]),
+                     "gather_rows_ms_min": float(t[4]), "pairs": float(t[5])} for r, t in enumerate(allr)]
     # HBM traffic cannot be read inside the run (PMC counters need rocprofv3): it is PROFILE-DERIVED, from the
     # committed summary of `rocprofv3 --pmc` passes over this same command, and says so
-    for prof_name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for prof_name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         prof = os.path.join(ROOT, "profiles", prof_name)
-        if os.path.exists(prof):
+        if os.path.exists(prof) and world == 1 and not fake:
             try:
                 tr = json.load(open(prof))
                 roofline["traffic"] = hbm["traffic"] = tr.get("hbm_bytes_per_launch")
@@ -273,16 +275,27 @@ def main():
             except Exception:
                 pass
 
-    # sanity: the gathered matrix must be the full P x P on every rank, and the greedy loop on it must undo the
-    # patch scramble: every scrambled patch ends with one sign, every untouched patch with the other
+    # sanity: the gathered matrix must be the full P x P on every rank, and the greedy loop on it must reproduce the
+    # REFERENCE's own run on this cloud (tests/golden/G19: visit order, flips and the chosen interactions of
+    # field_utils.strongest_field_propagation, start patch = the reference's) and undo the patch scramble: every
+    # scrambled patch ends with one sign, every untouched patch with the other
     signs_ok = None
+    trace_matches_reference = chosen_dev = None
     if not (fake > 1 and world == 1):
         assert W.shape == (N_PATCHES, N_PATCHES)
-        _, sigma, _ = fu._greedy_on_device(W, torch.zeros(1, dtype=torch.int64, device=dev))
+        g19_path = os.path.join(ROOT, "tests", "golden", "G19_headline_sphere_patch_propagation.npz")
+        g19 = np.load(g19_path) if os.path.exists(g19_path) else None
+        start = int(g19["order"][0]) if g19 is not None else 0
+        order, sigma, chosen = fu._greedy_on_device(W, torch.full((1,), start, dtype=torch.int64, device=dev))
         sigma = sigma.cpu().numpy()
         flipped_sign, kept_sign = sigma[scramble], sigma[~scramble]
         signs_ok = bool(np.all(flipped_sign == flipped_sign[0]) and np.all(kept_sign == kept_sign[0])
                         and flipped_sign[0] == -kept_sign[0])
+        if g19 is not None:
+            order = order.cpu().numpy()
+            trace_matches_reference = bool(
+                np.array_equal(order, g19["order"]) and np.array_equal(sigma[order[1:]] < 0, g19["flipped"][1:]))
+            chosen_dev = float(np.max(np.abs(chosen.cpu().numpy() - g19["chosen"]) / np.abs(g19["chosen"])))
 
     out = None
     if rank == 0:
@@ -296,7 +309,10 @@ def main():
                           "patches": N_PATCHES, "pairs_per_step": pairs_total,
                           "parallelism": f"patch-sharded x{world}, " + ("RCCL" if backend == "nccl" else backend) +
                                          " all-gather of W rows"},
-               "roofline": roofline, "hbm": hbm, "signs_ok": signs_ok}
+               "roofline": roofline, "hbm": hbm, "step_parts": step_parts, "signs_ok": signs_ok,
+               "trace_matches_reference_G19": trace_matches_reference, "chosen_max_rel_dev_vs_G19": chosen_dev}
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if fake > 1 and world == 1:
             out["fake_world"] = fake          # NOT a measurement of `fake` GPUs: one rank's share on one GPU
         if world > 1 and backend != "nccl":
@@ -311,7 +327,7 @@ def main():
         fu.flush_warnings()
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
 
 

@@ -281,7 +281,7 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
         pa.nonfinite = nonfinite;
         // the far-field chain only pays for spatially sorted clouds; its per-workgroup set-up (box scan + barrier) is
         // noise for big problems and a measurable 5-10 % for small ones (fandisk): off below 10^9 pairs
-        pa.far_d2 = (eps > F(0) && (double)S * (double)T >= DNP_K1_FAR_FROM) ? (F)pow((double)eps / kFarRatio, 2.0 / 3.0) : F(0);
+        pa.far_d2 = ((double)S * (double)T >= DNP_K1_FAR_FROM) ? (F)far_threshold_d2((double)eps) : F(0);
         for (int i = 0; i <= n_chunks; ++i) pa.chunk_off[i] = r.chunk_off[i];
         const dim3 grid((unsigned)t_tiles, (unsigned)n_chunks);
         // eps > 0 (what every caller of the reference passes): the short chain; otherwise the explicit one

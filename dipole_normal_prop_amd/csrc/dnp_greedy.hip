@@ -285,12 +285,15 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_kernel(const F* _
     }
 }
 
-// stream-ordered behind the persistent kernel: pts[:, 3:6] = n_out
+// stream-ordered behind the persistent kernel: pts[:, 3:6] = n_out - unless the persistent kernel gave up
+// (status[0] != 0: a workgroup timed out waiting for its peers; n_out then holds a partial propagation and pts must
+// stay the caller's input, because the host falls back to step-wise launches on it)
 template <typename F>
 __global__ __launch_bounds__(256) void store_normals_kernel(F* __restrict__ pts, int64_t ld,
-                                                            const F* __restrict__ n_out, int64_t N) {
+                                                            const F* __restrict__ n_out, int64_t N,
+                                                            const int* __restrict__ status) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    if (i >= N || status[0] != 0) return;
     F* p = pts + i * ld;
     p[3] = n_out[i * 3 + 0]; p[4] = n_out[i * 3 + 1]; p[5] = n_out[i * 3 + 2];
 }
@@ -514,7 +517,8 @@ static int run_point_greedy(F* pts, int64_t N, int64_t ld_pts, int64_t start, F 
     DNP_REQUIRE(start >= 0 && start < N, "starting_point %lld out of range [0,%lld)", (long long)start, (long long)N);
     DNP_REQUIRE(N < (int64_t)kIdxMask, "N=%lld exceeds the %u points of the persistent per-point kernel",
                 (long long)N, kIdxMask - 1);
-    DNP_REQUIRE(form >= 0 && form <= 2, "form=%d (0 auto, 1 single workgroup, 2 one workgroup per CU)", form);
+    DNP_REQUIRE(form >= 0 && form <= 3, "form=%d (0 auto, 1 single workgroup, 2 one workgroup per CU, 3 = 2 with the "
+                "time-out raised before the launch: test hook for the abort path)", form);
     const size_t need = kGreedyHeader + kGreedySlots + (size_t)N * 3 * sizeof(F);
     if (!workspace || workspace_bytes < need) {
         set_error("workspace of %zu bytes required, %zu given", need, workspace ? workspace_bytes : (size_t)0);
@@ -527,7 +531,7 @@ static int run_point_greedy(F* pts, int64_t N, int64_t ld_pts, int64_t start, F 
     // (IEEE div/sqrt chain: 1.1 us per step at 256 points, 2.4 at 2048, 4.2 at 4096 in fp32); one workgroup per CU
     // pays 2.2-2.4 us per step (3 in fp64) for the granule all-gather whatever the size.  Measured crossover
     // (tools/gpu_k4_forms.py): just below 2048 points in fp32, ~1500 in fp64.
-    bool multi = (form == 2) || (form == 0 && N > (sizeof(F) == 8 ? 1536 : 1792));
+    bool multi = (form >= 2) || (form == 0 && N > (sizeof(F) == 8 ? 1536 : 1792));
     if (form == 1) DNP_REQUIRE(N <= (int64_t)kGreedyThreads * kMaxPPT, "N=%lld exceeds the %d points of the single-workgroup form",
                                (long long)N, kGreedyThreads * kMaxPPT);
     if (N > (int64_t)kGreedyThreads * kMaxPPT) multi = true;
@@ -558,6 +562,9 @@ static int run_point_greedy(F* pts, int64_t N, int64_t ld_pts, int64_t start, F 
                     kMaxPPT);
         // tags start at step 0: every slot must hold a tag that no early step uses
         DNP_CHECK_HIP(hipMemsetAsync(slots, 0xff, kGreedySlots, st));
+        // form 3: the status word says "timed out" before the kernel starts - the first workgroup that has to wait for a
+        // granule leaves, then all do; what a time-out in the field looks like, on demand (tests)
+        if (form == 3) DNP_CHECK_HIP(hipMemsetAsync(status, 1, 1, st));
         MultiArgs<F> ma{pts, N, ld_pts, (int)start, eps, diffuse, order_out, E_out, n_out, slots, status, (int)per};
         // Co-residency: the all-gather may only wait for workgroups that are on the chip.  One workgroup per CU at
         // most, and the occupancy query must confirm that a CU holds one (the check hipLaunchCooperativeKernel would
@@ -584,7 +591,7 @@ static int run_point_greedy(F* pts, int64_t N, int64_t ld_pts, int64_t start, F 
 #undef DNP_LAUNCH_MULTI
     }
     hipLaunchKernelGGL((store_normals_kernel<F>), dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, st, pts, ld_pts,
-                       (const F*)n_out, N);
+                       (const F*)n_out, N, (const int*)status);
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
 }

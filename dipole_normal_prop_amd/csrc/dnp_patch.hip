@@ -138,7 +138,7 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts, cons
         pa.tgt = pts; pa.ld_tgt = ld_pts; pa.tgt_idx = nullptr; pa.T = N;
         pa.chunk_off_dev = patch_off; pa.chunk_base = p_begin + k0; pa.tgt_group = point_patch;
         pa.eps = eps; pa.partial = dE + k0 * N * 3;
-        pa.far_d2 = eps > 0.f ? (float)pow((double)eps / kFarRatio, 2.0 / 3.0) : 0.f;
+        pa.far_d2 = (float)far_threshold_d2((double)eps);
 #ifdef DNP_FAR_D2   // timing experiments only: force the far test (1e30f = never far, -1.f = always far)
         pa.far_d2 = DNP_FAR_D2;
 #endif

@@ -178,6 +178,13 @@ __device__ __forceinline__ void pair_field(F sx, F sy, F sz, F px, F py, F pz, F
 #define DNP_FAR_RATIO 4e-3
 #endif
 constexpr double kFarRatio = DNP_FAR_RATIO;
+// Host side: the squared box distance from which the far chains run; 0 switches them off.  They need a normal-range
+// threshold: for a tiny eps (< 1e-30) far_d2 would admit pairs whose u^3 = rsq(d2)^3 overflows fp32 (then e = eps*inf
+// and w = NaN where the exact chain returns a finite 1/(|r|^3+eps)), so such calls keep the exact chain.
+constexpr double kFarMinEps = 1e-30;
+static inline double far_threshold_d2(double eps) {
+    return eps >= kFarMinEps ? __builtin_pow(eps / kFarRatio, 2.0 / 3.0) : 0.0;
+}
 
 template <typename F>
 __device__ __forceinline__ void pair_field_far(F sx, F sy, F sz, F px, F py, F pz, F tx, F ty, F tz, F eps,

@@ -40,6 +40,9 @@ PATCH_MODE = "auto"
 SLAB_BUDGET_BYTES = 48 << 30
 # block size of the slab evaluation once the slabs do not fit that budget at once
 SLAB_BLOCK_BYTES = 16 << 30
+# slab sets up to this size are allocated without asking the driver how much memory is free (the query costs more
+# than a small propagation)
+SLAB_FREE_CHECK_BYTES = 1 << 30
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -177,7 +180,9 @@ class _WarnState:
 
     def next_slot(self, stream):
         """(device pointer, None) of the slot of one call launched on `stream` (an integer handle)."""
-        if self.head - self.tail >= _WARN_RING:                       # every slot is in flight: wait for the oldest
+        with self.lock:
+            full = self.head - self.tail >= _WARN_RING                # every slot is in flight: wait for the oldest
+        if full:
             self.drain(block=True)
         with self.lock:
             i = self.head % _WARN_RING
@@ -423,10 +428,15 @@ def _flattest_patch(pts: torch.Tensor, patches) -> torch.Tensor:
 
 
 def _start_tensor(work, patches, start_patch) -> torch.Tensor:
+    """The start patch as a 1-element device tensor.  A Python int is range-checked here (IndexError, as the host
+    loop greedy_order_from_interactions would raise); a TENSOR start is not synchronised on: the greedy kernels clamp
+    an out-of-range value to patch 0 (documented in include/dnp.h)."""
     if start_patch is None:
         return _flattest_patch(work, patches)
     if isinstance(start_patch, torch.Tensor):
         return start_patch.to(device=work.device, dtype=torch.int64).reshape(1)
+    if not 0 <= int(start_patch) < len(patches):
+        raise IndexError(f"start_patch {int(start_patch)} out of range for {len(patches)} patches")
     return torch.tensor([int(start_patch)], dtype=torch.int64, device=work.device)
 
 
@@ -696,8 +706,12 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
     per_slab = N * 3 * 4
     n_local = max(p_hi - p_lo, 1)
     budget = SLAB_BUDGET_BYTES
-    if n_local * per_slab > budget:
-        budget = max(budget, int(0.8 * _free_device_bytes(dev)))
+    if n_local * per_slab > SLAB_FREE_CHECK_BYTES:
+        # anything sizeable is checked against what the device really has free (a GPU shared by several ranks, a
+        # smaller part): within min(SLAB_BUDGET_BYTES, 80 % of free) one pass; beyond SLAB_BUDGET_BYTES the budget
+        # becomes 80 % of free
+        free = int(0.8 * _free_device_bytes(dev))
+        budget = min(budget, free) if n_local * per_slab <= budget else free
     if n_local * per_slab <= budget:
         batch = n_local
     else:

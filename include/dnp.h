@@ -171,10 +171,12 @@ int dnp_combine_fields_f32(const float* dE, int64_t K, int64_t N,
  * float64 clouds to this driver (util.py:71-77, socket_server.py:18-27).
  *
  * form: 0 = choose by N, 1 = single workgroup (N <= 512*20 fp32 / 512*8 fp64), 2 = one workgroup per CU
- * (co-residency checked against the occupancy query; N < 2^20).  max_groups > 0 caps the workgroup count of form 2.  The first int of the
+ * (co-residency checked against the occupancy query; N < 2^20), 3 = form 2 with the time-out raised before the
+ * launch (test hook for the abort path).  max_groups > 0 caps the workgroup count of form 2.  The first int of the
  * workspace is a status word: non-zero after the launch means a workgroup of form 2 gave up waiting for its
- * peers (GPU shared with another process); pts is then unchanged garbage-free input and the caller should fall
- * back to step-wise launches of dnp_field_grad.
+ * peers (GPU shared with another process); the copy kernel then stores nothing, so pts is bit for bit the caller's
+ * input (order_out / E_out hold a partial run) and the caller should fall back to step-wise launches of
+ * dnp_field_grad.
  */
 size_t dnp_point_greedy_workspace_bytes(int64_t N, int elem_size /* 4 or 8 */);
 int dnp_point_greedy_max_points(void);   /* capacity of the persistent forms: N < this */

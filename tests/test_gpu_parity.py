@@ -290,6 +290,47 @@ def test_patch_boxes_and_boxed_fields(dev):
     assert rel_rowwise(boxed[k].cpu()[rows], ref64) < TOL
 
 
+@pytest.mark.parametrize("eps", [1e-40, 1e-33, 1e-30, 3e-12])
+def test_far_chain_is_safe_for_tiny_eps(dev, eps):
+    """Round-2 advisor finding: with a denormal / tiny eps the far-field threshold (eps / 4e-3)^(2/3) admitted pairs whose
+    1/|r|^3 overflows fp32 and the one-transcendental chain returned NaN -> a silently zeroed slab row, where the exact
+    chain (and the reference) return a finite field.  Such eps now keep the exact chain (far_threshold_d2); checked on
+    the two launchers that enable the far path - the boxed patch slabs and a >= 10^9-pair field_grad - against fp64.
+    The cloud has near-coincident neighbours (spacing 1e-6..1e-3) next to ordinary ones."""
+    gen = torch.Generator().manual_seed(11)
+    base = torch.rand(4096, 3, generator=gen) - 0.5
+    near = base[:2048] + 10.0 ** (-6 + 3 * torch.rand(2048, 1, generator=gen)) * torch.randn(2048, 3, generator=gen)
+    xyz = torch.cat([base, near])
+    order = torch.argsort(torch.floor((xyz[:, 0] + 0.5) * 8) * 64 + torch.floor((xyz[:, 1] + 0.5) * 8) * 8 +
+                          torch.floor((xyz[:, 2] + 0.5) * 8))                       # 512 spatial cells = patches
+    xyz = xyz[order]
+    nrm = torch.randn(xyz.shape[0], 3, generator=gen)
+    cloud = torch.cat([xyz, nrm / nrm.norm(dim=1, keepdim=True)], 1).contiguous()
+    N = cloud.shape[0]
+    P = 48
+    off_np = np.linspace(0, N, P + 1).astype(np.int64)
+    off = t(off_np).to(dev)
+    swork = cloud.to(dev)
+    point_patch = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
+    boxes = fu._patch_boxes(swork, off, None)
+    dE = fu._patch_slabs(swork, off, None, point_patch, 0, P, eps, boxes)
+    assert bool(torch.isfinite(dE).all())
+    for k in (0, 23, P - 1):
+        others = (point_patch != k).cpu()
+        ref = c_oracle.field_grad_f64(cloud[off_np[k]:off_np[k + 1]].numpy(), cloud[others].numpy(), eps=eps)
+        got = dE[k].cpu()[others]
+        assert int((got.abs().sum(-1) == 0).sum()) == 0, "a finite field was zeroed"
+        assert rel_rowwise(got, ref) < 1e-4          # near-coincident pairs: 1/|r|^3 ~ 1e21, fp32 cancellation rows
+    # the generic entry point from 10^9 pairs on (32 768 x 32 768 replicas of the cloud, jittered)
+    big = torch.cat([cloud] * 6)[:32768].clone()
+    big[:, :3] += 1e-4 * torch.randn(32768, 3, generator=gen)
+    E = fu.field_grad(big.to(dev), big.to(dev), eps=eps).cpu()
+    rows = torch.arange(0, 32768, 257)
+    ref = c_oracle.field_grad_f64(big.numpy(), big[rows].numpy(), eps=eps)
+    assert bool(torch.isfinite(E).all()) and int((E[rows].abs().sum(-1) == 0).sum()) == 0
+    assert rel_rowwise(E[rows], ref) < 1e-4
+
+
 def test_patch_fields_interactions_and_combine(dev):
     g = load_golden("G6_patch_propagation")
     pts = t(g["pc_patchflip"]).to(dev)
@@ -395,6 +436,7 @@ def test_G6_slabs_larger_than_the_memory_budget(dev, tag, monkeypatch):
     per_slab = cloud.shape[0] * 12
     monkeypatch.setattr(fu, "PATCH_MODE", "batched")
     monkeypatch.setattr(fu, "SLAB_BUDGET_BYTES", 20 * per_slab)
+    monkeypatch.setattr(fu, "SLAB_FREE_CHECK_BYTES", 0)
     monkeypatch.setattr(fu, "_free_device_bytes", lambda dev: int(24.5 * per_slab / 0.8))     # budget 24 slabs: blocks of 12
     calls = []
     real = fu._patch_slabs
@@ -414,6 +456,42 @@ def test_G6_slabs_larger_than_the_memory_budget(dev, tag, monkeypatch):
     out = pts.cpu()
     assert np.array_equal(((out[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g[f"sign_{tag}"])
     assert np.abs(out[:, 3:].numpy() - g[f"normals_{tag}"]).max() < 1e-6
+
+
+def test_G6_slabs_within_the_budget_but_not_within_free_memory(dev, monkeypatch):
+    """A GPU shared by several ranks (or a smaller part): the slabs are inside SLAB_BUDGET_BYTES but the device has
+    less than that free - the driver must take the blocked two-pass path instead of one allocation that cannot
+    succeed (round-2 advisor finding)."""
+    g = load_golden("G6_patch_propagation")
+    tag = "sc_d_nw"
+    cloud, patches, allp, diffuse, w = _patch_case(g, tag)
+    per_slab = cloud.shape[0] * 12
+    monkeypatch.setattr(fu, "PATCH_MODE", "batched")
+    monkeypatch.setattr(fu, "SLAB_FREE_CHECK_BYTES", 0)
+    monkeypatch.setattr(fu, "_free_device_bytes", lambda dev: int(24.5 * per_slab / 0.8))     # 72 slabs wanted, 24 fit
+    calls = []
+    real = fu._patch_slabs
+    monkeypatch.setattr(fu, "_patch_slabs", lambda *a, **k: (calls.append((a[4], a[5])), real(*a, **k))[1])
+    pts = cloud.clone().to(dev)
+    allp_dev = [p.to(dev) for p in allp]
+    fu.strongest_field_propagation(pts, [(i, allp_dev[i]) for i, _ in patches], allp_dev, diffuse=diffuse)
+    assert len(calls) > 1 and max(b - a for a, b in calls) <= 12
+    tr = fu.last_trace("patches")
+    assert np.array_equal(tr["order"], g[f"order_{tag}"])
+    assert np.array_equal(((pts.cpu()[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g[f"sign_{tag}"])
+
+
+def test_start_patch_out_of_range_is_an_error(dev):
+    """A Python-int start patch outside [0, P) raises like the host loop would (round-2 advisor finding: the device
+    greedy kernels clamp, which produced a valid-looking but different propagation)."""
+    g = load_golden("G6_patch_propagation")
+    cloud, patches, allp, diffuse, w = _patch_case(g, "pf_n_nw")
+    pts = cloud.clone().to(dev)
+    allp_dev = [p.to(dev) for p in allp]
+    for bad in (-1, len(allp), 10 ** 6):
+        with pytest.raises(IndexError):
+            fu.strongest_field_propagation(pts, [(i, allp_dev[i]) for i, _ in patches], allp_dev, start_patch=bad)
+    assert torch.equal(pts.cpu(), cloud)
 
 
 @pytest.mark.parametrize("tag", ["pf_d_nw", "sc_n_w"])
@@ -791,6 +869,39 @@ def test_point_greedy_never_reads_a_rewritten_normal(dev):
         torch.cuda.synchronize()
         assert int(ws[:4].view(torch.int32).item()) == 0
         assert torch.equal(work, ref), (form, groups)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_point_greedy_timeout_leaves_pts_untouched_and_the_fallback_equals_the_kernel(dev, dtype, monkeypatch, capsys):
+    """The abort path of the multi-workgroup form (a workgroup gave up waiting for its peers), forced with the ABI's
+    test hook form = 3: the status word is set, pts stays bit for bit the caller's input (the copy kernel stores
+    nothing - round 2 stored a partial propagation and could hand the fallback a globally inverted start), and the
+    Python driver's step-wise fallback ends exactly where the persistent kernel does."""
+    lib = _lib.require_device()
+    g = load_golden("G8_point_propagation")
+    cloud = t(g["pc_sub1000"]).to(dev).to(dtype)
+    N = cloud.shape[0]
+    work = cloud.clone()
+    order = torch.full((N,), -1, dtype=torch.int64, device=dev)
+    nbytes = lib.dnp_point_greedy_workspace_bytes(N, work.element_size())
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    fn = lib.dnp_point_greedy_f64 if dtype == torch.float64 else lib.dnp_point_greedy_f32
+    rc = fn(_lib.ptr(work), N, 6, 0, 1e-6, 1, _lib.ptr(order), None, 3, 4, _lib.ptr(ws), nbytes, _lib.current_stream())
+    assert rc == 0, lib.dnp_last_error()
+    torch.cuda.synchronize()
+    assert int(ws[:4].view(torch.int32).item()) != 0, "form 3 must end in the time-out state"
+    assert torch.equal(work, cloud), "an aborted launch must leave pts untouched"
+    # the driver: same hook, falls back to the step-wise launches and warns
+    good = cloud.clone()
+    fu.strongest_field_propagation_points(good, diffuse=True)
+    good_order = fu.last_trace("points")["order"]
+    monkeypatch.setattr(fu, "POINT_GREEDY_FORM", 3)
+    monkeypatch.setattr(fu, "POINT_GREEDY_GROUPS", 4)
+    fell = cloud.clone()
+    fu.strongest_field_propagation_points(fell, diffuse=True)
+    assert "timed out" in capsys.readouterr().out
+    assert np.array_equal(fu.last_trace("points")["order"], good_order)
+    assert torch.equal(fell, good)
 
 
 def test_nonfinite_leaf_components_are_counted_and_zeroed(dev, capsys):

@@ -774,6 +774,40 @@ def g18(fu, util):
          out3_rows=out3_rows)
 
 
+def g19(fu, util):
+    """The HEADLINE workload itself (BASELINE config 4 = bench.py's cloud, tools/workloads.headline_workload): the
+    100 000-point sphere (seed 1234), 256 Fibonacci patches, whole patches sign-scrambled (seed 0), run through the
+    reference's strongest_field_propagation (field_utils.py:286-348) with diffuse=True and every patch in the
+    filtered list - 10^10 pair evaluations in the reference.  Stored: its start patch, the complete visit order, the
+    flip decisions, the chosen interaction of every step, the 100 000 final signs, the per-patch curvatures it chose
+    the start from, and - as the pin of the bench's dominant kernel - the reference's own
+    field_grad(pts[patch_k], pts[~patch_k]) for three patches (all ~99 600 rows each).  The inputs are rebuilt from
+    the seeds by tools/workloads.py; a checksum of them is stored."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.workloads import headline_workload
+    pc, allp, scramble = headline_workload()
+    patches = list(enumerate(allp))
+    out = dict(pc_head=pc[:16], pc_sum=pc.double().sum(0), scramble=scramble,
+               sizes=np.array([len(p) for p in allp]))
+    slab_patches = np.array([0, 100, 255])
+    for k in slab_patches:
+        mask = torch.zeros(len(pc), dtype=torch.bool)
+        mask[allp[k]] = True
+        out[f"dE_{k}"] = fu.field_grad(pc[allp[k]], pc[~mask])
+    out["slab_patches"] = slab_patches
+    out["curv"] = np.array([util.pca_eigen_values(pc[p])[0].item() for p in allp])
+    t0 = time.time()
+    pts, calls, inter = _run_patch_driver(fu, util, "patch", pc, patches, allp, True, None)
+    print(f"  reference patch propagation on the headline cloud: {time.time() - t0:.1f}s")
+    firsts = [(int(p[0]), pc[int(p[0]), :3]) for p in allp]
+    mins = [(int(p.min()), pc[int(p.min()), :3]) for p in allp]
+    order, flipped = _order_from_calls(calls, pc, firsts, mins)
+    assert (np.sort(order) == np.arange(len(allp))).all(), "every patch visited exactly once"
+    out.update(order=order, flipped=flipped, chosen=np.array([float(t[t.abs().argmax()]) for t in inter]),
+               sign=np.packbits(((pts[:, 3:] * pc[:, 3:]).sum(-1) > 0).numpy()))
+    save("G19_headline_sphere_patch_propagation", **out)
+
+
 def make_inference_shim():
     """inference_utils.py imports models/ (torch_geometric, absent offline) at module level.
     Only its pure-torch fix_n_filter is on the path; load that one function's source object by
@@ -789,7 +823,7 @@ def make_inference_shim():
     spec.loader.exec_module(mod)
 
 
-ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13, G14=g14, G15=g15, G16=g16, GW=gw, GX2=gx2, G17=g17, G18=g18)
+ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13, G14=g14, G15=g15, G16=g16, GW=gw, GX2=gx2, G17=g17, G18=g18, G19=g19)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
