@@ -42,3 +42,31 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda:0")
+
+
+# `chosen` = the interaction of the patch picked at each greedy step.  The reference accumulates E in fp32 in visit
+# order and sums the patch in fp32; the drivers sum fp64 W entries.  CHOSEN_RTOL = 10 x the worst deviation measured
+# over every golden trace (profiles/r03_chosen_deviation.txt: 5.4e-6 on G6's point-scrambled fandisk cloud, where the
+# late interactions are cancellation residues; <= 6.3e-7 on every 100 000-point trace), relative to |chosen|.
+# Rounds 1-2 used 2e-4 with no measurement behind it.
+CHOSEN_RTOL = 6e-5
+_chosen_log = []
+
+
+def check_chosen(got, want, label):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    dev = np.abs(got - want) / np.abs(want)
+    _chosen_log.append((label, float(dev.max()), int(dev.argmax()), len(want)))
+    assert dev.max() <= CHOSEN_RTOL, (label, float(dev.max()))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _chosen_log:
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "chosen_deviation.txt"), "w") as f:
+                f.write("# max |chosen - golden| / |golden| per golden trace (label, worst, step, steps)\n")
+                for row in _chosen_log:
+                    f.write("%-40s %.3e  step %d of %d\n" % row)
+        except OSError:
+            pass

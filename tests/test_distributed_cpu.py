@@ -139,3 +139,50 @@ def test_gather_rows_single_process_is_identity():
     W = torch.arange(12, dtype=torch.float64).view(3, 4)
     assert torch.equal(parallel.gather_rows(W, np.array([0, 3])), W)
     assert parallel.world() == (0, 1)
+
+
+def _gather_worker(rank, world, port, sizes, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dipole_normal_prop_amd import field_utils as fu
+        P = len(sizes)
+        W = torch.from_numpy(np.random.default_rng(5).standard_normal((P, P)))          # the same matrix on every rank
+        bounds = fu._balanced_blocks(np.asarray(sizes), world)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        full = parallel.gather_rows(W[lo:hi].clone(), bounds)
+        E = parallel.reduce_field(torch.full((7, 3), float(rank + 1), dtype=torch.float64))
+        start = parallel.agree_on_start(torch.tensor([rank + 40]))
+        q.put((rank, bool(torch.equal(full, W)), float(E[0, 0]), int(start[0]), bounds.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["headline_256_even", "ragged_61"])
+def test_world8_gather_rows_reduce_and_start_agreement(kind):
+    """north_star's shape: 8 ranks.  The collectives of parallel.py on 8 gloo ranks - the all-gather of the W rows with
+    the headline workload's patch sizes (256 patches -> equal blocks of 32) and with ragged sizes (61 patches -> uneven
+    blocks, the padded all-gather) must rebuild the single-process matrix on every rank; the all-reduce sums all eight
+    partial fields; every rank ends with rank 0's start patch."""
+    if kind == "headline_256_even":
+        sizes = load_golden("G19_headline_sphere_patch_propagation")["sizes"].tolist()
+    else:
+        sizes = (np.random.default_rng(2).integers(1, 900, 61)).tolist()
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, sizes, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    bounds = np.array(res[0][4])
+    assert bounds[0] == 0 and bounds[-1] == len(sizes) and np.all(np.diff(bounds) >= 0)
+    if kind == "headline_256_even":
+        assert np.all(np.diff(bounds) == 32)
+    else:
+        assert len(set(np.diff(bounds).tolist())) > 1
+    for rank, same, esum, start, b in res:
+        assert same, f"rank {rank}: gathered matrix differs from the single-process W"
+        assert esum == sum(range(1, world + 1)) and start == 40 and b == bounds.tolist()

@@ -152,15 +152,9 @@ def test_G11_recursion_leaves():
 
 
 def sphere100k():
-    gen = torch.Generator().manual_seed(1234)
-    x = torch.randn(100000, 3, generator=gen)
-    n = x / x.norm(dim=-1, keepdim=True)
-    pc = torch.cat([n, n], dim=1)
-    center = pc[:, :3].mean(dim=0)
-    scale = (pc[:, :3].max(dim=0)[0] - pc[:, :3].min(dim=0)[0]).max()
-    pc[:, :3] -= center[None, :]
-    pc[:, :3] = pc[:, :3] / scale
-    return pc
+    """The headline cloud - ONE definition, shared with bench.py and the golden generator (tools/workloads.py)."""
+    from tools.workloads import sphere_cloud
+    return sphere_cloud()
 
 
 def test_G12_sphere_generator_and_rows():
@@ -172,6 +166,33 @@ def test_G12_sphere_generator_and_rows():
     assert rel_rowwise(E64, g["E64_rows"][:8]) < F64_TOL
     assert rel_rowwise(g["E_rows"][:8], E64) < 2e-6
     assert float(g["mean_potential"]) > 0                     # outward normals -> positive mean potential
+
+
+def test_G19_headline_workload_and_oracle_slab_rows():
+    """G19 pins the bench workload against the reference: the inputs rebuilt from the seeds are the generator's (head
+    rows, column sums, patch sizes, scramble), and the oracles reproduce the reference's own
+    field_grad(pts[patch_k], pts[~patch_k]) - the dense-broadcast port on a row sample within fp32 rounding, the fp64 C
+    arbiter on every row of one slab within the reference's own fp32 error."""
+    from tools.workloads import headline_workload
+    g = load_golden("G19_headline_sphere_patch_propagation")
+    pc, patches, scramble = headline_workload()
+    assert np.array_equal(pc[:16].numpy(), g["pc_head"]) and np.allclose(pc.double().sum(0).numpy(), g["pc_sum"], rtol=0, atol=1e-9)
+    assert np.array_equal(np.array([len(p) for p in patches]), g["sizes"]) and np.array_equal(scramble, g["scramble"])
+    assert sorted(g["order"].tolist()) == list(range(256)) and g["chosen"].shape == (255,)
+    k = int(g["slab_patches"][1])
+    mask = torch.ones(pc.shape[0], dtype=torch.bool)
+    mask[patches[k]] = False
+    others = pc[mask]
+    ref = g[f"dE_{k}"]
+    assert ref.shape == (others.shape[0], 3)
+    rows = np.arange(0, others.shape[0], 97)
+    E_port = O.field_grad(pc[patches[k]], others[rows])
+    assert rel_rowwise(E_port, ref[rows]) < 2e-6
+    E64 = c_oracle.field_grad_f64(pc[patches[k]].numpy(), others.numpy())
+    assert rel_rowwise(ref, E64) < 2e-6
+    # the start-patch rule on the reference's own curvatures: a clear minimum (no tie class on this cloud)
+    c = np.abs(g["curv"])
+    assert int(np.argmin(c)) == int(g["order"][0]) and np.sort(c)[1] / np.sort(c)[0] > 1.03
 
 
 # ---- greedy drivers ---------------------------------------------------------------------------------
