@@ -178,6 +178,7 @@ def main():
     point_patch = torch.repeat_interleave(torch.arange(N_PATCHES, device=dev), off[1:] - off[:-1])
     idx = None
     boxes = fu._patch_boxes(pts, off, idx)       # per-cloud set-up like the CSR offsets (the drivers do the same once)
+    tiles = fu._TileTables(pts, sizes)           # target-tile boxes; W rows out of the pair kernel's epilogue if tiles allow
     bounds = fu._balanced_blocks(sizes, world)
     p_lo, p_hi = int(bounds[rank]), int(bounds[rank + 1])
     fake = int(os.environ.get("BENCH_FAKE_WORLD", "0"))      # developer aid: time one rank's share of an N-rank run
@@ -192,10 +193,20 @@ def main():
     def step(marks=None):
         if marks is not None:
             marks[0].record()
-        dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes)
+        if tiles.fused:              # what the drivers do (field_utils._slabs_and_rows), opened up for the event marks
+            w_part = torch.empty((p_hi - p_lo, tiles.n_tiles, 2), dtype=torch.float64, device=dev)
+            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part)
+        else:
+            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes)
         if marks is not None:
             marks[1].record()
-        W = fu._interaction_rows(dE, pts, off, idx)
+        if tiles.fused:
+            W = torch.empty((p_hi - p_lo, N_PATCHES), dtype=torch.float64, device=dev)
+            fu._lib.check(fu._lib.require_device().dnp_interactions_from_tiles(
+                fu._lib.ptr(w_part), p_hi - p_lo, N_POINTS, fu._lib.ptr(point_patch), fu._lib.ptr(off), N_PATCHES,
+                fu._lib.ptr(W), fu._lib.current_stream()))
+        else:
+            W = fu._interaction_rows(dE, pts, off, idx)
         if marks is not None:
             marks[2].record()
         W = parallel.gather_rows(W, bounds)
@@ -241,7 +252,7 @@ def main():
                 "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VALU_PEAK_TFLOPS,
                 "traffic": None, "launch_ms": k_ms, "launch_ms_median": k_med, "launch_ms_min": k_min,
                 "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": launch_pairs,
-                "timed": f"HIP events around dnp_patch_fields_boxed_f32 (one pair_kernel_scalar launch) on torch's current "
+                "timed": f"HIP events around dnp_patch_fields_tiled_f32 (one pair_kernel_scalar launch) on torch's current "
                          f"stream, recorded inside the {args.steps} timed steps; achieved = 33 flop x pairs_per_launch / "
                          f"mean launch_ms",
                 "note": "FP32 vector ALU binds (no MFMA on this path); peak equals the dense f32 MFMA peak; 33 flop "
@@ -250,6 +261,8 @@ def main():
            "frac": algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
            "traffic": None}
     step_parts = {"pair_kernel_ms": k_ms, "interactions_kernel_ms": float(k3_all.mean()),
+                  "interactions_from": "pair-kernel epilogue partials + dnp_interactions_from_tiles" if tiles.fused
+                  else "dnp_interactions_f32 (second pass over the slabs)",
                   "gather_rows_ms": float(ag_all.mean())}
     per_rank = None
     if world > 1:

@@ -19,6 +19,9 @@ constexpr int kPatchScalarKT = 2;         // scalar kernel (patch-sorted cloud):
 #define DNP_FAR 1
 #endif
 constexpr bool kPatchFar = DNP_FAR != 0;
+#ifndef DNP_FORCE_LDS   // A/B builds only (tools/gpu_ab_far.py): 1 sends the sorted layout through the LDS kernel too
+#define DNP_FORCE_LDS 0
+#endif
 
 // W[k][j] = sum_{t in patch j} dE[k][t] . n_t    - one workgroup per (j, k), fp64 tree reduce.
 __global__ __launch_bounds__(256) void interactions_kernel(const float* __restrict__ dE, int64_t N,
@@ -93,9 +96,76 @@ __global__ __launch_bounds__(256) void patch_box_kernel(const float* __restrict_
         boxes[p * 6 + 3 + c] = h;
     }
 }
+
+// boxes of the target tiles: tile i = rows [i * rows_per_tile, (i + 1) * rows_per_tile) - what one wavefront of the
+// scalar-unit pair kernel owns (64 KT = 128 rows); one wavefront per tile
+__global__ __launch_bounds__(256) void tile_box_kernel(const float* __restrict__ pts, int64_t ld, int64_t N,
+                                                       int rows_per_tile, int64_t n_tiles, float* __restrict__ boxes) {
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const int lane = threadIdx.x & 63;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    const int64_t r0 = tile * rows_per_tile, r1 = (r0 + rows_per_tile < N) ? r0 + rows_per_tile : N;
+    for (int64_t q = r0 + lane; q < r1; q += 64) {
+        const float* r = pts + q * ld;
+        for (int c = 0; c < 3; ++c) { lo[c] = r[c] < lo[c] ? r[c] : lo[c]; hi[c] = r[c] > hi[c] ? r[c] : hi[c]; }
+    }
+    for (int c = 0; c < 3; ++c) { lo[c] = wave_min<float>(lo[c]); hi[c] = wave_max<float>(hi[c]); }
+    if (lane == 0)
+        for (int c = 0; c < 3; ++c) { boxes[tile * 6 + c] = lo[c]; boxes[tile * 6 + 3 + c] = hi[c]; }
+}
+
+// W[k][j] = sum over the target tiles that overlap patch j of the tile's partial for j (slot 0 when j is the group of
+// the tile's first row, else slot 1), in tile order - the second half of the fused interaction matrix
+__global__ __launch_bounds__(256) void tile_interactions_kernel(const double* __restrict__ w_part, int64_t n_tiles,
+                                                                int rows_per_tile, const int64_t* __restrict__ point_patch,
+                                                                const int64_t* __restrict__ patch_off, int64_t P,
+                                                                int64_t K, double* __restrict__ W) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (j >= P || k >= K) return;
+    const int64_t lo = patch_off[j], hi = patch_off[j + 1];
+    double s = 0.0;
+    if (hi > lo) {
+        const int64_t t0 = lo / rows_per_tile, t1 = (hi - 1) / rows_per_tile;
+        const double* part = w_part + k * n_tiles * 2;
+        for (int64_t t = t0; t <= t1; ++t) s += part[t * 2 + (point_patch[t * rows_per_tile] == j ? 0 : 1)];
+    }
+    W[k * P + j] = s;
+}
+
 }  // namespace dnp
 
 extern "C" {
+
+int dnp_tile_boxes_f32(const float* pts, int64_t N, int64_t ld_pts, int64_t rows_per_tile, float* boxes, void* stream) {
+    clear_error();
+    DNP_REQUIRE(N >= 0, "negative size");
+    DNP_REQUIRE(rows_per_tile > 0 && rows_per_tile <= 1 << 20, "rows_per_tile=%lld", (long long)rows_per_tile);
+    if (N == 0) return DNP_OK;
+    DNP_REQUIRE(pts && boxes, "NULL pointer");
+    DNP_REQUIRE(ld_pts >= 3, "ld_pts=%lld < 3", (long long)ld_pts);
+    const int64_t n_tiles = ceil_div(N, rows_per_tile);
+    hipLaunchKernelGGL(tile_box_kernel, dim3((unsigned)ceil_div(n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, pts, ld_pts,
+                       N, (int)rows_per_tile, n_tiles, boxes);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+int64_t dnp_patch_tile_rows(void) { return 64 * kPatchScalarKT; }
+
+int dnp_interactions_from_tiles(const double* w_part, int64_t K, int64_t N, const int64_t* point_patch,
+                                const int64_t* patch_off, int64_t P, double* W, void* stream) {
+    clear_error();
+    DNP_REQUIRE(K >= 0 && N >= 0 && P >= 0, "negative size");
+    if (K == 0 || P == 0) return DNP_OK;
+    DNP_REQUIRE(w_part && point_patch && patch_off && W, "NULL pointer");
+    DNP_REQUIRE(K <= 65535, "K=%lld slabs exceed one launch (65535)", (long long)K);
+    const int rows = 64 * kPatchScalarKT;
+    hipLaunchKernelGGL(tile_interactions_kernel, dim3((unsigned)ceil_div(P, 256), (unsigned)K), dim3(256), 0,
+                       (hipStream_t)stream, w_part, ceil_div(N, (int64_t)rows), rows, point_patch, patch_off, P, K, W);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
 
 int dnp_patch_boxes_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
                         const int64_t* patch_idx, int64_t P, float* boxes, void* stream) {
@@ -121,6 +191,14 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts, cons
                                const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
                                const float* patch_box, int64_t p_begin, int64_t p_end, float eps, float* dE,
                                void* stream) {
+    return dnp_patch_fields_tiled_f32(pts, N, ld_pts, patch_off, patch_idx, P, point_patch, patch_box, nullptr, p_begin,
+                                      p_end, eps, dE, nullptr, stream);
+}
+
+int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
+                               const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
+                               const float* patch_box, const float* tile_box, int64_t p_begin, int64_t p_end, float eps,
+                               float* dE, double* w_part, void* stream) {
     clear_error();
     DNP_REQUIRE(N >= 0 && P >= 0, "negative size");
     DNP_REQUIRE(0 <= p_begin && p_begin <= p_end && p_end <= P, "bad patch range [%lld,%lld) of %lld",
@@ -128,6 +206,10 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts, cons
     if (N == 0 || p_begin == p_end) return DNP_OK;
     DNP_REQUIRE(pts && patch_off && point_patch && dE, "NULL pointer");   // patch_idx may be NULL (contiguous)
     DNP_REQUIRE(ld_pts >= 6, "ld_pts=%lld < 6", (long long)ld_pts);
+    // the tile tables belong to the scalar-unit kernel on the patch-sorted layout with the far chain on
+    const bool scalar_path = !patch_idx && eps > 0.f && !DNP_FORCE_LDS;
+    DNP_REQUIRE(!w_part || (scalar_path && patch_box && tile_box && kPatchFar && far_threshold_d2((double)eps) > 0.0),
+                "w_part needs the patch-sorted layout (patch_idx == NULL), eps >= 1e-30 and both box tables");
     const int64_t t_tiles = ceil_div(N, (int64_t)kBlock * kPatchKT);
     const int64_t K = p_end - p_begin;
     // grid.y is limited to 65535 workgroups: walk the patch range in slices
@@ -143,14 +225,19 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts, cons
         pa.far_d2 = DNP_FAR_D2;
 #endif
         const hipStream_t st = (hipStream_t)stream;
-#ifndef DNP_FORCE_LDS   // A/B builds only (tools/gpu_ab_far.py): 1 sends the sorted layout through the LDS kernel too
-#define DNP_FORCE_LDS 0
-#endif
-        if (!patch_idx && eps > 0.f && !DNP_FORCE_LDS) {
+        if (scalar_path) {
             // patch-sorted cloud (what the drivers pass): contiguous sources -> the scalar-unit kernel
             const dim3 sgrid((unsigned)ceil_div(N, (int64_t)kBlock * kPatchScalarKT), (unsigned)kn);
             pa.chunk_box = patch_box;
-            if (patch_box && kPatchFar)
+            pa.tile_box = tile_box;
+            pa.w_part = w_part ? w_part + k0 * ceil_div(N, (int64_t)64 * kPatchScalarKT) * 2 : nullptr;
+            if (patch_box && tile_box && kPatchFar && pa.far_d2 > 0.f && w_part)
+                hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, true>),
+                                   sgrid, dim3(kBlock), 0, st, pa);
+            else if (patch_box && tile_box && kPatchFar && pa.far_d2 > 0.f)
+                hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true>),
+                                   sgrid, dim3(kBlock), 0, st, pa);
+            else if (patch_box && kPatchFar)
                 hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true>), sgrid,
                                    dim3(kBlock), 0, st, pa);
             else

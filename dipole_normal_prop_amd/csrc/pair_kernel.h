@@ -99,6 +99,8 @@ struct PairArgs {
     int* nonfinite;          // [2] counters of inf / nan leaf components zeroed (direct epilogue), or nullptr
     const F* chunk_box;      // [chunks][6] bounding boxes (lo xyz, hi xyz) of the chunks' sources, or nullptr: found by the workgroup
     F far_d2;                // scalar kernel, FAR: squared box distance beyond which the one-transcendental chain runs
+    const F* tile_box;       // scalar kernel, TBOX: [ceil(T / (64 KT))][6] boxes of the wavefronts' target tiles (dnp_tile_boxes_f32)
+    double* w_part;          // scalar kernel, WPART: [gridDim.y][ceil(T / (64 KT))][2] per-(slab, tile) interaction partials
     int32_t chunk_off[kMaxChunks + 1];  // by-value CSR offsets when chunk_off_dev == nullptr
 };
 
@@ -493,7 +495,12 @@ __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, cons
         }
 }
 
-template <typename F, typename PT, int MODE, int KT, int V, bool FAR = false, bool BOX = false>
+// TBOX: the box of a wavefront's 64 KT targets comes from a.tile_box (one table per cloud) instead of 36 cross-lane
+// min / max steps per (wavefront, chunk).  WPART (patch mode, cloud sorted by patch, every tile inside <= 2 groups): the
+// epilogue also leaves sum_t dE[t] . n_t of the tile's targets, split by group (the tile's first group / the other one),
+// in a.w_part - the patch interaction matrix W then needs no second pass over the slabs (dnp_interactions_from_tiles).
+template <typename F, typename PT, int MODE, int KT, int V, bool FAR = false, bool BOX = false, bool TBOX = false,
+          bool WPART = false>
 __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, PT> a) {
     using M = Math<F>;
     constexpr int NC = (MODE == kField) ? 3 : 1;
@@ -546,15 +553,22 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
                 for (int c = 0; c < 3; ++c) { chunk_box[tid >> 6][c] = lo[c]; chunk_box[tid >> 6][3 + c] = hi[c]; }
         }
         F tlo[3] = {M::kHuge, M::kHuge, M::kHuge}, thi[3] = {-M::kHuge, -M::kHuge, -M::kHuge};
+        if constexpr (TBOX) {
+            const int64_t wave_tile = (int64_t)blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);
+            const F* tb = a.tile_box + wave_tile * 6;                       // wave-uniform: scalar loads
 #pragma unroll
-        for (int k = 0; k < KT; ++k)
-            if (trow[k] >= 0) {
-                tlo[0] = tx[k] < tlo[0] ? tx[k] : tlo[0]; thi[0] = tx[k] > thi[0] ? tx[k] : thi[0];
-                tlo[1] = ty[k] < tlo[1] ? ty[k] : tlo[1]; thi[1] = ty[k] > thi[1] ? ty[k] : thi[1];
-                tlo[2] = tz[k] < tlo[2] ? tz[k] : tlo[2]; thi[2] = tz[k] > thi[2] ? tz[k] : thi[2];
-            }
+            for (int c = 0; c < 3; ++c) { tlo[c] = tb[c]; thi[c] = tb[3 + c]; }
+        } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { tlo[c] = wave_min<F>(tlo[c]); thi[c] = wave_max<F>(thi[c]); }
+            for (int k = 0; k < KT; ++k)
+                if (trow[k] >= 0) {
+                    tlo[0] = tx[k] < tlo[0] ? tx[k] : tlo[0]; thi[0] = tx[k] > thi[0] ? tx[k] : thi[0];
+                    tlo[1] = ty[k] < tlo[1] ? ty[k] : tlo[1]; thi[1] = ty[k] > thi[1] ? ty[k] : thi[1];
+                    tlo[2] = tz[k] < tlo[2] ? tz[k] : tlo[2]; thi[2] = tz[k] > thi[2] ? tz[k] : thi[2];
+                }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { tlo[c] = wave_min<F>(tlo[c]); thi[c] = wave_max<F>(thi[c]); }
+        }
         F d2box = F(0);
         if constexpr (given) {
             const F* b = a.chunk_box + (a.chunk_base + chunk) * 6;          // wave-uniform: scalar loads
@@ -638,12 +652,19 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
     }
 
     const int64_t chunk_id = a.chunk_base + chunk;
+    double w_first = 0.0, w_other = 0.0;                  // WPART: this lane's share of the tile's interaction sums
+    int64_t g_first = 0;
+    if constexpr (WPART) {                                  // group of the tile's first target (wave-uniform)
+        const int row0 = __builtin_amdgcn_readfirstlane((int)trow[0]);
+        g_first = row0 >= 0 ? a.tgt_group[row0] : -2;
+    }
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         const int64_t t = tile_base + (int64_t)(tid >> 6) * (64 * KT) + k * 64 + (tid & 63);   // a wave owns 64 KT consecutive targets
         if (t < a.T) {
             bool excluded = false;
-            if (a.tgt_group) excluded = (a.tgt_group[trow[k]] == chunk_id);
+            int64_t grp = -1;
+            if (a.tgt_group) { grp = a.tgt_group[trow[k]]; excluded = (grp == chunk_id); }
             if (a.out) {
                 F* o = a.out + (a.out_scatter ? trow[k] : t) * a.ld_out;
 #pragma unroll
@@ -657,13 +678,35 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
                 }
             } else {
                 PT* o = a.partial + ((int64_t)chunk * a.T + t) * NC;
+                PT vv[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     PT v = (PT)((MODE == kField) ? -acc[k][c] : acc[k][c]);
                     if (a.tgt_group && !__builtin_isfinite(v)) v = PT(0);
-                    o[c] = excluded ? PT(0) : v;
+                    vv[c] = excluded ? PT(0) : v;
+                    o[c] = vv[c];
+                }
+                if constexpr (WPART && MODE == kField) {
+                    // per-point dot in fp32 like (E[patch] * pts[patch, 3:]).sum(dim=-1) (field_utils.py:316), patch sums in fp64
+                    const F* n = a.tgt + trow[k] * a.ld_tgt + 3;
+                    const float d = (float)vv[0] * n[0] + (float)vv[1] * n[1] + (float)vv[2] * n[2];
+                    if (grp == g_first) w_first += (double)d; else w_other += (double)d;
                 }
             }
+        }
+    }
+    if constexpr (WPART && MODE == kField) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {             // fixed butterfly: the sums do not depend on anything but the tile
+            w_first += __shfl_xor(w_first, off, 64);
+            w_other += __shfl_xor(w_other, off, 64);
+        }
+        const int64_t n_tiles = (a.T + 64 * KT - 1) / (64 * KT);
+        const int64_t wave_tile = (int64_t)blockIdx.x * (kBlock / 64) + (tid >> 6);
+        if ((tid & 63) == 0 && wave_tile < n_tiles) {
+            double* wp = a.w_part + ((int64_t)chunk * n_tiles + wave_tile) * 2;
+            wp[0] = w_first;
+            wp[1] = w_other;
         }
     }
 }

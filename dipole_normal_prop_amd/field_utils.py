@@ -512,16 +512,62 @@ def _patch_boxes(work: torch.Tensor, off, idx) -> torch.Tensor:
     return boxes
 
 
-def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, eps: float, boxes=None) -> torch.Tensor:
+def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, eps: float, boxes=None, tile_boxes=None,
+                 w_part: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dE[p1 - p0, N, 3]: the fields of patches p0..p1 on every point (dnp_patch_fields_tiled_f32).  boxes / tile_boxes:
+    the per-cloud box tables of the far-field test (_patch_boxes, _tile_boxes); w_part: receives the per-tile
+    interaction partials (see _TileTables)."""
     lib = _lib.require_device()
     N = work.shape[0]
     dE = torch.empty((p1 - p0, N, 3), dtype=torch.float32, device=work.device)
     with _on_device(work.device):
-        rc = lib.dnp_patch_fields_boxed_f32(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
-                                            off.shape[0] - 1, _lib.ptr(point_patch), _lib.ptr(boxes), p0, p1, float(eps),
-                                            _lib.ptr(dE), _lib.current_stream())
+        rc = lib.dnp_patch_fields_tiled_f32(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
+                                            off.shape[0] - 1, _lib.ptr(point_patch), _lib.ptr(boxes), _lib.ptr(tile_boxes),
+                                            p0, p1, float(eps), _lib.ptr(dE), _lib.ptr(w_part), _lib.current_stream())
     _lib.check(rc)
     return dE
+
+
+class _TileTables:
+    """Per-cloud tables of the patch-sorted layout for the scalar-unit pair kernel: the boxes of its target tiles
+    (tile i = sorted rows [i R, (i+1) R), R = dnp_patch_tile_rows() = the 128 targets one wavefront owns) and whether
+    every tile lies inside at most two groups (patches; rows in no patch form the last group) - then the kernel's
+    epilogue can leave the interaction sums per (slab, tile, group slot) and W needs no second pass over the slabs."""
+    __slots__ = ("rows", "n_tiles", "boxes", "fused")
+
+    def __init__(self, swork: torch.Tensor, sizes: np.ndarray):
+        lib = _lib.require_device()
+        N = swork.shape[0]
+        self.rows = int(lib.dnp_patch_tile_rows())
+        self.n_tiles = -(-N // self.rows)
+        self.boxes = torch.empty((self.n_tiles, 6), dtype=torch.float32, device=swork.device)
+        with _on_device(swork.device):
+            _lib.check(lib.dnp_tile_boxes_f32(_lib.ptr(swork), N, swork.stride(0), self.rows, _lib.ptr(self.boxes),
+                                              _lib.current_stream()))
+        # group of the first and of the last row of every tile, from the patch sizes alone (host, no sync)
+        ends = np.cumsum(np.asarray(sizes, dtype=np.int64))           # rows >= ends[-1]: in no patch = one more group
+        first = np.arange(self.n_tiles, dtype=np.int64) * self.rows
+        last = np.minimum(first + self.rows, N) - 1
+        self.fused = bool(np.all(np.searchsorted(ends, last, side="right") - np.searchsorted(ends, first, side="right") <= 1))
+
+
+def _slabs_and_rows(swork, off, point_patch, b0: int, b1: int, eps: float, boxes, tiles: "_TileTables"):
+    """One evaluation of patches b0..b1 on the patch-sorted cloud: (dE[b1-b0, N, 3], W rows [b1-b0, P] fp64).  When the
+    tiles allow it the interaction rows come out of the pair kernel's epilogue (+ a tiny gather kernel), otherwise from
+    the K3 pass over the slabs."""
+    P = off.shape[0] - 1
+    if tiles is not None and tiles.fused and boxes is not None and eps >= 1e-30:
+        lib = _lib.require_device()
+        K, N = b1 - b0, swork.shape[0]
+        w_part = torch.empty((K, tiles.n_tiles, 2), dtype=torch.float64, device=swork.device)
+        dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, tiles.boxes, w_part)
+        W = torch.empty((K, P), dtype=torch.float64, device=swork.device)
+        with _on_device(swork.device):
+            _lib.check(lib.dnp_interactions_from_tiles(_lib.ptr(w_part), K, N, _lib.ptr(point_patch), _lib.ptr(off), P,
+                                                       _lib.ptr(W), _lib.current_stream()))
+        return dE, W
+    dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, None if tiles is None else tiles.boxes)
+    return dE, _interaction_rows(dE, swork, off, None)
 
 
 def _interaction_rows(dE, work, off, idx) -> torch.Tensor:
@@ -703,6 +749,7 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
     # the device has free (288 GB of HBM on an MI355X), the patches go through in blocks of at most SLAB_BLOCK_BYTES,
     # as many blocks as fit are kept, and only the others are evaluated a second time for the combine.
     boxes = _patch_boxes(swork, off, None)               # for the far-field test of the pair kernel
+    tiles = _TileTables(swork, sizes)                    # target-tile boxes; can W come out of the kernel's epilogue?
     per_slab = N * 3 * 4
     n_local = max(p_hi - p_lo, 1)
     budget = SLAB_BUDGET_BYTES
@@ -719,8 +766,8 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
     W_rows, kept, kept_bytes = [], {}, 0
     for b0 in range(p_lo, p_hi, batch):
         b1 = min(b0 + batch, p_hi)
-        dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes)
-        W_rows.append(_interaction_rows(dE, swork, off, None))
+        dE, rows = _slabs_and_rows(swork, off, point_patch, b0, b1, eps, boxes, tiles)
+        W_rows.append(rows)
         # keep this block if it and one more working block still fit
         if want_E and diffuse and kept_bytes + (b1 - b0) * per_slab + (batch * per_slab if b1 < p_hi else 0) <= budget:
             kept[b0] = dE
@@ -744,7 +791,7 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
             b1 = min(b0 + batch, p_hi)
             dE = kept.pop(b0, None)
             if dE is None:
-                dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes)
+                dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, None if tiles is None else tiles.boxes)
             _combine_signed(dE, sigma, b0, Es, not first)
             first = False
             del dE

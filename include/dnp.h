@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DNP_VERSION 201 /* 0.2.1 */
+#define DNP_VERSION 300 /* 0.3.0 */
 
 enum {
     DNP_OK = 0,
@@ -138,6 +138,31 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts,
                                const int64_t* point_patch, const float* patch_box,
                                int64_t p_begin, int64_t p_end, float eps,
                                float* dE, void* stream);
+
+/* The drivers' form (round 3): the patch-sorted layout only (patch_idx must be NULL for the tables to be used), with
+ *   tile_box[ceil(N / R)][6]  boxes of the target tiles, tile i = rows [i R, (i+1) R), R = dnp_patch_tile_rows() = the 128
+ *                             rows one wavefront of the kernel owns (dnp_tile_boxes_f32; NULL = the wavefront finds the
+ *                             box of its targets itself, 36 cross-lane steps per (wavefront, patch)), and
+ *   w_part[p_end-p_begin][ceil(N / R)][2]  (optional, NULL = not wanted) the interaction sums of every tile:
+ *       w_part[k][i][0] = sum_{t in tile i, patch(t) == patch(first row of tile i)} dE[k][t] . n_t
+ *       w_part[k][i][1] = the same over the tile's other rows
+ *     (fp32 dot per point as the reference's (E[patch] * pts[patch, 3:]).sum(dim=-1), field_utils.py:316, fp64 sums in a
+ *     fixed order).  With every tile inside at most two groups (patches of >= R points; rows in no patch last) W follows
+ *     from dnp_interactions_from_tiles without a second pass over the 12 N P bytes of slabs; the caller checks that
+ *     condition (the drivers do, on the host, from the patch sizes) and uses dnp_interactions_f32 otherwise.
+ * dE is bit-identical with dnp_patch_fields_boxed_f32's; w_part requires eps >= 1e-30 and both tables.
+ */
+int64_t dnp_patch_tile_rows(void);
+int dnp_tile_boxes_f32(const float* pts, int64_t N, int64_t ld_pts, int64_t rows_per_tile, float* boxes, void* stream);
+int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts,
+                               const int64_t* patch_off, const int64_t* patch_idx, int64_t P,
+                               const int64_t* point_patch, const float* patch_box, const float* tile_box,
+                               int64_t p_begin, int64_t p_end, float eps,
+                               float* dE, double* w_part, void* stream);
+/* W[k][j] = sum of w_part[k][i][slot] over the tiles i that overlap patch j (slot 0 when j is the patch of the tile's
+ * first row), in tile order; W is [K, P] doubles.  Same quantity as dnp_interactions_f32 up to fp64 reassociation. */
+int dnp_interactions_from_tiles(const double* w_part, int64_t K, int64_t N, const int64_t* point_patch,
+                                const int64_t* patch_off, int64_t P, double* W, void* stream);
 
 /* ---- K3: patch interaction matrix -----------------------------------------------------
  *

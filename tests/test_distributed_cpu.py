@@ -23,7 +23,7 @@ class OracleStandIn:
     itself has no such switch."""
 
     @staticmethod
-    def slabs(work, off, idx, point_patch, b0, b1, eps, boxes=None):
+    def slabs(work, off, idx, point_patch, b0, b1, eps, boxes=None, tile_boxes=None, w_part=None):
         N = work.shape[0]
         idx = torch.arange(N) if idx is None else idx        # None: cloud sorted by patch
         dE = torch.zeros(b1 - b0, N, 3)
@@ -89,6 +89,7 @@ def _worker(rank, world, port, start, q):
         from dipole_normal_prop_amd import field_utils as fu
         fu._patch_slabs, fu._interaction_rows = OracleStandIn.slabs, OracleStandIn.interactions
         fu._patch_boxes = lambda work, off, idx: None                            # only the device kernel reads them
+        fu._TileTables = lambda swork, sizes: None
         fu._greedy_on_device, fu._combine_signed = OracleStandIn.greedy, OracleStandIn.combine_signed
         fu._finish_batched = OracleStandIn.finish
         fu._prepare_work = lambda p, w: (p.detach().clone().float(), None)       # CPU working copy (no weights here)

@@ -290,6 +290,76 @@ def test_patch_boxes_and_boxed_fields(dev):
     assert rel_rowwise(boxed[k].cpu()[rows], ref64) < TOL
 
 
+def test_tile_tables_and_fused_interaction_rows(dev):
+    """Round 3: the target-tile box table and the interaction partials of the pair kernel's epilogue.
+    dnp_tile_boxes_f32 equals per-tile min / max; the slabs are bit-identical with and without the tile table and with
+    and without the partials; W assembled from the partials (dnp_interactions_from_tiles) equals the K3 pass over the
+    slabs up to fp64 reassociation - on boxunion (369 patches of >= 100 points: some 128-row tiles straddle three
+    patches, so the driver must refuse the fused form there) and on a cut with patches of >= 128 points plus rows
+    that are in no patch (fused form allowed)."""
+    lib = _lib.require_device()
+    g = load_golden("G15_boxunion_config3")
+    cloud = t(g["pc"]).to(dev)
+    off_np, idx_np = g["patch_off"].astype(np.int64), g["patch_idx"].astype(np.int64)
+    swork = cloud[t(idx_np).to(dev)].contiguous()
+    N = swork.shape[0]
+    R = int(lib.dnp_patch_tile_rows())
+    assert R == 128
+    tiles = fu._TileTables(swork, np.diff(off_np))
+    ref = torch.stack([torch.cat([swork[i:i + R, :3].min(0).values, swork[i:i + R, :3].max(0).values]) for i in range(0, N, R)])
+    assert tiles.n_tiles == ref.shape[0] and torch.equal(tiles.boxes, ref)
+    assert not tiles.fused                               # min patch 100 < 128 rows: a tile can hold three patches
+    off = t(off_np).to(dev)
+    P = len(off_np) - 1
+    point_patch = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
+    boxes = fu._patch_boxes(swork, off, None)
+    boxed = fu._patch_slabs(swork, off, None, point_patch, 100, 140, 1e-5, boxes)
+    tiled = fu._patch_slabs(swork, off, None, point_patch, 100, 140, 1e-5, boxes, tiles.boxes)
+    assert torch.equal(boxed, tiled)
+    dE, W = fu._slabs_and_rows(swork, off, point_patch, 100, 140, 1e-5, boxes, tiles)     # falls back to K3
+    assert torch.equal(dE, boxed) and torch.equal(W, fu._interaction_rows(boxed, swork, off, None))
+
+    # a cut that allows the fused form: patches of 128..700 rows over the first 90 000 rows, the rest in no patch
+    rng = np.random.default_rng(3)
+    sizes = []
+    while sum(sizes) < 90000:
+        sizes.append(int(rng.integers(128, 700)))
+    sizes[-1] -= sum(sizes) - 90000
+    if sizes[-1] < 128:
+        sizes[-2] += sizes.pop()
+    sizes = np.array(sizes + [0, 300], dtype=np.int64)    # an empty patch and a last one
+    off2_np = np.concatenate([[0], np.cumsum(sizes)])
+    off2 = t(off2_np).to(dev)
+    P2 = len(sizes)
+    covered = int(off2_np[-1])
+    pp2 = torch.cat([torch.repeat_interleave(torch.arange(P2, device=dev), off2[1:] - off2[:-1]),
+                     torch.full((N - covered,), -1, dtype=torch.int64, device=dev)])
+    tiles2 = fu._TileTables(swork, sizes)
+    assert not tiles2.fused                               # the empty patch makes a tile's group ids jump by two: refused
+    sizes3 = np.array(sizes[:-2].tolist() + [300], dtype=np.int64)
+    off3_np = np.concatenate([[0], np.cumsum(sizes3)])
+    off3 = t(off3_np).to(dev)
+    P3 = len(sizes3)
+    pp3 = torch.cat([torch.repeat_interleave(torch.arange(P3, device=dev), off3[1:] - off3[:-1]),
+                     torch.full((N - int(off3_np[-1]),), -1, dtype=torch.int64, device=dev)])
+    tiles3 = fu._TileTables(swork, sizes3)
+    assert tiles3.fused
+    boxes3 = fu._patch_boxes(swork, off3, None)
+    for b0, b1 in ((0, P3), (7, 31)):
+        dE, W = fu._slabs_and_rows(swork, off3, pp3, b0, b1, 1e-5, boxes3, tiles3)
+        plain = fu._patch_slabs(swork, off3, None, pp3, b0, b1, 1e-5, boxes3)
+        assert torch.equal(dE, plain)
+        W3 = fu._interaction_rows(plain, swork, off3, None)
+        assert W.shape == W3.shape == (b1 - b0, P3)
+        assert float((W - W3).abs().max()) <= 1e-12 * float(W3.abs().max())
+        assert float(W[:, :].abs().max()) > 0
+    # every (slab, patch) entry is the plain definition: fp32 dot per point, fp64 sum over the patch
+    k = 11
+    d32 = (dE[k - 7][:, 0] * swork[:, 3] + dE[k - 7][:, 1] * swork[:, 4] + dE[k - 7][:, 2] * swork[:, 5]).double()
+    want = torch.stack([d32[off3_np[j]:off3_np[j + 1]].sum() for j in range(P3)])
+    assert float((W[k - 7] - want).abs().max()) <= 1e-6 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("eps", [1e-40, 1e-33, 1e-30, 3e-12])
 def test_far_chain_is_safe_for_tiny_eps(dev, eps):
     """Round-2 advisor finding: with a denormal / tiny eps the far-field threshold (eps / 4e-3)^(2/3) admitted pairs whose

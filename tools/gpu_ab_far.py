@@ -17,7 +17,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import fibonacci_patches, sphere_cloud  # noqa: E402
+from tools.workloads import fibonacci_patches, sphere_cloud  # noqa: E402
 from dipole_normal_prop_amd import _lib, build, util  # noqa: E402
 from oracle import c_oracle  # noqa: E402
 
@@ -26,9 +26,11 @@ NOFAR = os.path.join(ROOT, "tools", "bin", "libdnp_nofar.so")
 
 def bind(path):
     lib = ctypes.CDLL(path)
-    for fn in ("dnp_patch_fields_f32", "dnp_patch_fields_boxed_f32", "dnp_patch_boxes_f32"):
-        res, args = _lib.SIGNATURES[fn]
-        getattr(lib, fn).restype, getattr(lib, fn).argtypes = res, args
+    for fn in ("dnp_patch_fields_f32", "dnp_patch_fields_boxed_f32", "dnp_patch_boxes_f32", "dnp_patch_fields_tiled_f32",
+               "dnp_tile_boxes_f32", "dnp_interactions_from_tiles", "dnp_interactions_f32"):
+        if hasattr(lib, fn):
+            res, args = _lib.SIGNATURES[fn]
+            getattr(lib, fn).restype, getattr(lib, fn).argtypes = res, args
     return lib
 
 
@@ -60,7 +62,14 @@ def main():
     pts = pc.to(dev)[idx].contiguous()
     N, P = pts.shape[0], len(sizes)
     point_patch = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
-    libs["nobox"] = libs["far"]
+    libs["nobox"] = libs["far"]       # run-time variants of the product library: no patch-box table,
+    libs["tiled"] = libs["far"]       # + target-tile box table,
+    libs["tiledw"] = libs["far"]      # + interaction partials in the epilogue
+    n_tiles = (N + 127) // 128
+    tile_boxes = torch.empty((n_tiles, 6), dtype=torch.float32, device=dev)
+    assert libs["far"].dnp_tile_boxes_f32(_lib.ptr(pts), N, 6, 128, _lib.ptr(tile_boxes),
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    w_part = torch.empty((P, n_tiles, 2), dtype=torch.float64, device=dev)
     boxes = torch.empty((P, 6), dtype=torch.float32, device=dev)
     assert libs["far"].dnp_patch_boxes_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(boxes),
                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
@@ -71,6 +80,11 @@ def main():
         if name == "nobox":          # the product library without the box table: every workgroup finds its patch's box
             rc = libs[name].dnp_patch_fields_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch), 0, P,
                                                  1e-5, _lib.ptr(dE[name]), stream)
+        elif name in ("tiled", "tiledw"):
+            rc = libs[name].dnp_patch_fields_tiled_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch),
+                                                       _lib.ptr(boxes), _lib.ptr(tile_boxes), 0, P, 1e-5,
+                                                       _lib.ptr(dE[name]), _lib.ptr(w_part) if name == "tiledw" else None,
+                                                       stream)
         else:
             rc = libs[name].dnp_patch_fields_boxed_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch),
                                                        _lib.ptr(boxes), 0, P, 1e-5, _lib.ptr(dE[name]), stream)
@@ -94,6 +108,23 @@ def main():
         print(f"{name:6s} median {np.median(ts):.3f} ms  min {ts.min():.3f}  max {ts.max():.3f}  "
               f"({1e10 / np.median(ts) / 1e9:.3f} Tpairs/s, roofline frac {33e10 / (np.median(ts) * 1e-3) / 157.3e12:.3f})")
     print(f"far / exact = {np.median(times['far']) / np.median(times['exact']):.4f}")
+    for name in ("nobox", "tiled", "tiledw"):
+        print(f"{name} slabs bit-identical to far: {bool(torch.equal(dE[name], dE['far']))}")
+    # the fused interaction matrix against the K3 pass over the slabs
+    W3 = torch.empty((P, P), dtype=torch.float64, device=dev)
+    Wt = torch.empty((P, P), dtype=torch.float64, device=dev)
+    assert libs["far"].dnp_interactions_f32(_lib.ptr(dE["far"]), P, N, _lib.ptr(pts), 6, _lib.ptr(off), None, P, _lib.ptr(W3), stream) == 0
+    assert libs["far"].dnp_interactions_from_tiles(_lib.ptr(w_part), P, N, _lib.ptr(point_patch), _lib.ptr(off), P, _lib.ptr(Wt), stream) == 0
+    torch.cuda.synchronize()
+    print(f"W from tiles vs K3: max |diff| / max |W| = {float((Wt - W3).abs().max() / W3.abs().max()):.2e}")
+    for label, fn in (("K3 dnp_interactions_f32", lambda: libs["far"].dnp_interactions_f32(_lib.ptr(dE["far"]), P, N, _lib.ptr(pts), 6, _lib.ptr(off), None, P, _lib.ptr(W3), stream)),
+                      ("dnp_interactions_from_tiles", lambda: libs["far"].dnp_interactions_from_tiles(_lib.ptr(w_part), P, N, _lib.ptr(point_patch), _lib.ptr(off), P, _lib.ptr(Wt), stream))):
+        ts = []
+        for _ in range(20):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) * 1e3)
+        print(f"{label}: median {np.median(ts):.1f} us  min {min(ts):.1f}")
 
     # accuracy on a row sample: summed field of all patches (= all-pairs field minus the own-patch part) vs fp64
     rows = np.arange(0, N, 997)
