@@ -29,6 +29,10 @@ SIGNATURES = {
                                          _c_i64, _c_p, _c_sz, _c_p]),
     "dnp_potential_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p,
                                          _c_i64, _c_p, _c_sz, _c_p]),
+    "dnp_reference_field_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, ctypes.c_int, ctypes.c_float, _c_i64,
+                                               _c_p, _c_i64, _c_p, _c_p, _c_sz, _c_p]),
+    "dnp_reference_field_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, ctypes.c_int, ctypes.c_double, _c_i64,
+                                               _c_p, _c_i64, _c_p, _c_p, _c_sz, _c_p]),
     "dnp_patch_fields_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64,
                                             ctypes.c_float, _c_p, _c_p]),
     "dnp_patch_boxes_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p]),

@@ -208,11 +208,60 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs<F> a) {
     *o = a.accumulate ? (F)(*o + v) : v;
 }
 
+// ---- reduce with the tail of field_utils.reference_field (field_utils.py:188-201) fused in: one thread per target row.
+//   kTailNormalise  out[t] = (x, y, z, E / |E|)   (rows with |E| == 0 keep E)                    :191-194, 3-column targets
+//   kTailSign       n_t *= (E . n_t >= 0 ? +1 : -1), in place on the target rows' columns 3..5   :195-199, 6-column targets
+// The field itself is summed exactly as reduce_kernel does (per leaf: chunk sums in fp64 in chunk order, rounded to F,
+// non-finite components zeroed and counted; leaves added in fp64).  The per-point products are rounded separately and
+// added left to right, as torch's (E * n).sum(dim=-1) does - no fma contraction: a sign decision hangs on it.
+enum RefTail { kTailNormalise = 1, kTailSign = 2 };
+
+template <typename F, int TAIL>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const ReduceArgs<F> a, F* __restrict__ tgt, int64_t ld_tgt) {
+#pragma clang fp contract(off)
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.T) return;
+    const int64_t stride = a.T * 3;
+    F e[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double total = 0.0;
+        for (int l = 0; l < a.n_leaves; ++l) {
+            double s = 0.0;
+            const int c1 = a.leaf_first[l + 1];
+            for (int ch = a.leaf_first[l]; ch < c1; ch += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (ch + u < c1) ? a.partial[(int64_t)(ch + u) * stride + t * 3 + c] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            const F f = (F)s;
+            if (__builtin_isfinite(f)) total += (double)f;
+            else if (a.nonfinite) atomicAdd(a.nonfinite + (f != f ? 1 : 0), 1);
+        }
+        e[c] = (F)total;
+    }
+    F* row = tgt + t * ld_tgt;
+    if (TAIL == kTailNormalise) {
+        F* o = a.out + t * a.ld_out;
+        const F len = __builtin_sqrt((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);      // IEEE sqrt / division
+        const F den = (len != F(0)) ? len : F(1);
+        o[0] = row[0]; o[1] = row[1]; o[2] = row[2];
+        o[3] = e[0] / den; o[4] = e[1] / den; o[5] = e[2] / den;
+    } else {
+        const F d = (e[0] * row[3] + e[1] * row[4]) + e[2] * row[5];
+        const F sg = (d >= F(0)) ? F(1) : F(-1);                                      // `>=`: reference_field, not the drivers' `>`
+        row[3] = row[3] * sg; row[4] = row[4] * sg; row[5] = row[5] * sg;
+    }
+}
+
 template <typename F, int MODE>
 static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
                      const F* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
                      F eps, int64_t max_pts, F* out, int64_t ld_out, int out_scatter, int accumulate,
-                     int* nonfinite, int* nonfinite_host, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                     int* nonfinite, int* nonfinite_host, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                     int tail = 0, F* tgt_rw = nullptr) {
     constexpr int NC = (MODE == kField) ? 3 : 1;
     clear_error();
     DNP_REQUIRE(S >= 0 && T >= 0, "negative size S=%lld T=%lld", (long long)S, (long long)T);
@@ -222,13 +271,23 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
             DNP_CHECK_HIP(hipMemcpyAsync(nonfinite_host, nonfinite, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
         return DNP_OK;
     }
-    DNP_REQUIRE(tgt && out, "NULL tgt/out pointer");
+    DNP_REQUIRE(tgt && (out || tail == kTailSign), "NULL tgt/out pointer");
     DNP_REQUIRE(S == 0 || src, "NULL src pointer");
     DNP_REQUIRE(ld_src >= 6 || S == 0, "ld_src=%lld < 6", (long long)ld_src);
     DNP_REQUIRE(ld_tgt >= 3, "ld_tgt=%lld < 3", (long long)ld_tgt);
     DNP_REQUIRE(ld_out >= (MODE == kField ? 3 : 1), "ld_out=%lld too small", (long long)ld_out);
     DNP_REQUIRE(!out_scatter || tgt_idx, "out_scatter requires tgt_idx");
 
+    if (S == 0 && tail != 0) {  // empty sum: E = 0 -> the tails see a zero field (normals (0,0,0) / sign +1)
+        ReduceArgs<F> ra{};
+        ra.partial = nullptr; ra.T = T; ra.tgt_idx = nullptr; ra.out = out; ra.ld_out = ld_out; ra.n_leaves = 0;
+        if (tail == kTailNormalise)
+            hipLaunchKernelGGL((reduce_rows_kernel<F, kTailNormalise>), dim3((unsigned)ceil_div(T, 256)), dim3(256), 0, stream, ra, tgt_rw, ld_tgt);
+        else
+            hipLaunchKernelGGL((reduce_rows_kernel<F, kTailSign>), dim3((unsigned)ceil_div(T, 256)), dim3(256), 0, stream, ra, tgt_rw, ld_tgt);
+        DNP_CHECK_HIP(hipGetLastError());
+        return DNP_OK;
+    }
     if (S == 0) {  // empty sum: zeros (the reference's sum over an empty dim)
         if (nonfinite && nonfinite_host)
             DNP_CHECK_HIP(hipMemcpyAsync(nonfinite_host, nonfinite, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -266,6 +325,11 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
     }
     const int64_t t_tiles = ceil_div(T, (int64_t)kBlock * plan.kt);
     DNP_REQUIRE(t_tiles <= INT32_MAX, "T too large");
+    if (tail != 0 && plan.rounds.size() != 1) {
+        set_error("reference_field tail: %zu rounds of chunks (S=%lld, T=%lld) - call dnp_field_grad and finish on the caller's side",
+                  plan.rounds.size(), (long long)S, (long long)T);
+        return DNP_EINVAL;
+    }
 
     bool first = true;
     for (const auto& r : plan.rounds) {
@@ -276,11 +340,14 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
         pa.chunk_off_dev = nullptr; pa.chunk_base = 0; pa.tgt_group = nullptr;
         pa.eps = eps; pa.partial = (double*)workspace;
         // one chunk that is also the only leaf of the only round: the pair kernel writes the final rows
-        const bool direct = plan.rounds.size() == 1 && n_chunks == 1;
+        const bool direct = plan.rounds.size() == 1 && n_chunks == 1 && tail == 0;
         pa.out = direct ? out : nullptr; pa.ld_out = ld_out; pa.out_scatter = out_scatter; pa.accumulate = accumulate;
         pa.nonfinite = nonfinite;
         // the far-field chain only pays for spatially sorted clouds; its per-workgroup set-up (box scan + barrier) is
-        // noise for big problems and a measurable 5-10 % for small ones (fandisk): off below 10^9 pairs
+        // noise for big problems and a measurable 5-10 % for small ones (fandisk): off below 10^9 pairs.  (Round 3
+        // measured the boxes from two pre-kernels instead - a chunk table and a target-tile table as in patch mode:
+        // 4452.6 against 4448.3 us at 100 000^2 on the patch-sorted cloud, no gain: with 780-source chunks the scan is
+        // already amortised and the two extra launches cost what the tables save; profiles/r03_k1_tables_ab.txt.)
         pa.far_d2 = ((double)S * (double)T >= DNP_K1_FAR_FROM) ? (F)far_threshold_d2((double)eps) : F(0);
         for (int i = 0; i <= n_chunks; ++i) pa.chunk_off[i] = r.chunk_off[i];
         const dim3 grid((unsigned)t_tiles, (unsigned)n_chunks);
@@ -327,7 +394,15 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
         ra.n_leaves = (int)r.leaf_first.size() - 1;
         for (int i = 0; i <= ra.n_leaves; ++i) ra.leaf_first[i] = r.leaf_first[i];
         const int64_t n = T * NC;
-        hipLaunchKernelGGL((reduce_kernel<F, NC>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, ra);
+        if (tail != 0 && MODE == kField) {
+            // reference_field: a plan of one round (checked above), field summed and consumed in one pass
+            if (tail == kTailNormalise)
+                hipLaunchKernelGGL((reduce_rows_kernel<F, kTailNormalise>), dim3((unsigned)ceil_div(T, 256)), dim3(256), 0, stream, ra, tgt_rw, ld_tgt);
+            else
+                hipLaunchKernelGGL((reduce_rows_kernel<F, kTailSign>), dim3((unsigned)ceil_div(T, 256)), dim3(256), 0, stream, ra, tgt_rw, ld_tgt);
+        } else {
+            hipLaunchKernelGGL((reduce_kernel<F, NC>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, ra);
+        }
         DNP_CHECK_HIP(hipGetLastError());
         first = false;
     }
@@ -376,6 +451,28 @@ int dnp_field_grad_f64(const double* src, int64_t S, int64_t ld_src, const int64
     return run_pairs<double, kField>(src, S, ld_src, src_idx, tgt, T, ld_tgt, tgt_idx, eps, max_pts, out, ld_out,
                                      out_scatter, accumulate, nonfinite, nonfinite_host, workspace, workspace_bytes,
                                      (hipStream_t)stream);
+}
+
+int dnp_reference_field_f32(const float* src, int64_t S, int64_t ld_src, float* tgt, int64_t T, int64_t ld_tgt,
+                            int form, float eps, int64_t max_pts, float* out, int64_t ld_out, int32_t* nonfinite,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    clear_error();
+    DNP_REQUIRE(form == kTailNormalise || form == kTailSign, "form=%d (1 = 3-column targets -> out[T,6], 2 = 6-column targets, in place)", form);
+    DNP_REQUIRE(form == kTailNormalise ? (out && ld_out >= 6) : ld_tgt >= 6, "form %d needs %s", form,
+                form == kTailNormalise ? "out[T, >=6]" : "6-column target rows");
+    return run_pairs<float, kField>(src, S, ld_src, nullptr, tgt, T, ld_tgt, nullptr, eps, max_pts, out, ld_out, 0, 0, nonfinite,
+                                    nullptr, workspace, workspace_bytes, (hipStream_t)stream, form, tgt);
+}
+
+int dnp_reference_field_f64(const double* src, int64_t S, int64_t ld_src, double* tgt, int64_t T, int64_t ld_tgt,
+                            int form, double eps, int64_t max_pts, double* out, int64_t ld_out, int32_t* nonfinite,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    clear_error();
+    DNP_REQUIRE(form == kTailNormalise || form == kTailSign, "form=%d (1 = 3-column targets -> out[T,6], 2 = 6-column targets, in place)", form);
+    DNP_REQUIRE(form == kTailNormalise ? (out && ld_out >= 6) : ld_tgt >= 6, "form %d needs %s", form,
+                form == kTailNormalise ? "out[T, >=6]" : "6-column target rows");
+    return run_pairs<double, kField>(src, S, ld_src, nullptr, tgt, T, ld_tgt, nullptr, eps, max_pts, out, ld_out, 0, 0, nonfinite,
+                                     nullptr, workspace, workspace_bytes, (hipStream_t)stream, form, tgt);
 }
 
 int dnp_potential_f32(const float* src, int64_t S, int64_t ld_src, const int64_t* src_idx,

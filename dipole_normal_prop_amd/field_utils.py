@@ -369,8 +369,15 @@ def random_self_interaction(nxyz, eps=1e-5):
 def reference_field(pc1, pc2):
     """Transfer orientation from an oriented cloud pc1[S,6] to pc2 (field_utils.py:188-201):
     3-column pc2 -> returns cat([xyz, E/|E|]) (rows with |E| == 0 keep E); 6-column pc2 -> normals
-    multiplied in place by sign(E.n) with `>= 0` counting as +1."""
+    multiplied in place by sign(E.n) with `>= 0` counting as +1.
+
+    Device tensors of one float dtype go through ONE library call (dnp_reference_field_*: the normalisation / the sign
+    flip happen in the reduction pass of the field kernel); anything else takes the field from field_grad and finishes
+    with the reference's own torch expressions."""
     with torch.no_grad():
+        fused = _reference_field_fused(pc1, pc2)
+        if fused is not None:
+            return fused
         E = field_grad(pc1, pc2, recursive=True)
         if pc2.shape[1] == 3:
             length = E.norm(dim=-1)
@@ -382,6 +389,43 @@ def reference_field(pc1, pc2):
             sign = (interactions >= 0).to(pc2.dtype) * 2 - 1
             pc2[:, 3:] = pc2[:, 3:] * sign[:, None]
         return pc2
+
+
+_REF_FIELD_MAX_SOURCES = 200_000     # one round of source chunks in the library (beyond: field_grad + torch tail)
+
+
+def _reference_field_fused(pc1, pc2):
+    """The one-call form, or None when the inputs are not two device tensors of the same float32 / float64 dtype with
+    unit inner stride (pc2 with 3 or 6 columns).  The 6-column form writes pc2's normals in place."""
+    if not (pc1.is_cuda and pc2.is_cuda and pc1.device == pc2.device and pc1.dtype == pc2.dtype
+            and pc1.dtype in (torch.float32, torch.float64) and pc1.dim() == 2 and pc2.dim() == 2
+            and pc1.shape[1] >= 6 and pc2.shape[1] in (3, 6) and 0 < pc1.shape[0] <= _REF_FIELD_MAX_SOURCES
+            and pc2.shape[0] > 0 and pc2.stride(1) == 1 and pc2.stride(0) >= pc2.shape[1]):
+        return None
+    lib = _lib.require_device()
+    dev = pc1.device
+    src = _stage(pc1.detach(), dev, pc1.dtype)
+    S, T = src.shape[0], pc2.shape[0]
+    form = 1 if pc2.shape[1] == 3 else 2
+    out = torch.empty((T, 6), dtype=pc2.dtype, device=dev) if form == 1 else None
+    nbytes = _WS_BYTES.get(("field", S, T, 15000))
+    if nbytes is None:
+        nbytes = _WS_BYTES[("field", S, T, 15000)] = lib.dnp_field_grad_workspace_bytes(S, T, 15000)
+    handle = torch.cuda.current_stream(dev).cuda_stream
+    ws = _workspace(nbytes, dev, handle)
+    st = _warn_state(dev)
+    if st.batches:
+        st.drain()
+    slot = st.next_slot(handle)
+    fn = lib.dnp_reference_field_f64 if pc1.dtype == torch.float64 else lib.dnp_reference_field_f32
+    with _on_device(dev):
+        rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(pc2), T, _ld(pc2), form, 1e-5, 15000, _lib.ptr(out),
+                6, slot[0], _lib.ptr(ws), ws.numel(), ctypes.c_void_p(handle))
+    st.after_call()
+    if rc != 0 and b"rounds of chunks" in lib.dnp_last_error():
+        return None                      # a source / target set beyond one round of chunks: nothing was launched
+    _lib.check(rc)
+    return out if form == 1 else pc2
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -99,6 +99,22 @@ int dnp_potential_f64(const double* src, int64_t S, int64_t ld_src, const int64_
                       int64_t max_pts, double* out, int64_t ld_out,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- reference_field  (field_utils.reference_field, field_utils.py:188-201) as ONE call: the field of the oriented
+ *      cloud src[S, >=6] at the rows of tgt, and the function's tail fused into the reduction pass:
+ *   form 1 (3-column targets, :191-194): out[T, >=6] = (x, y, z, E / |E|), rows with |E| == 0 keep E (zeros);
+ *   form 2 (6-column targets, :195-199): tgt[:, 3:6] *= (E . n >= 0 ? +1 : -1) IN PLACE (note `>=`; out is not used).
+ * The per-point products are rounded separately and added left to right (no fma contraction), as torch's
+ * (E * n).sum(dim=-1).  Workspace as dnp_field_grad (dnp_field_grad_workspace_bytes(S, T, max_pts)).  Returns DNP_EINVAL
+ * when the source set needs more than one round of chunks (beyond ~260 000 recursion-leaf sources): the caller then
+ * uses dnp_field_grad and finishes itself.  nonfinite as in dnp_field_grad (device int32[3], may be NULL).
+ */
+int dnp_reference_field_f32(const float* src, int64_t S, int64_t ld_src, float* tgt, int64_t T, int64_t ld_tgt,
+                            int form, float eps, int64_t max_pts, float* out, int64_t ld_out, int32_t* nonfinite,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int dnp_reference_field_f64(const double* src, int64_t S, int64_t ld_src, double* tgt, int64_t T, int64_t ld_tgt,
+                            int form, double eps, int64_t max_pts, double* out, int64_t ld_out, int32_t* nonfinite,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- batched per-patch fields: the multi-GPU shard unit --------------------------------
  *
  * For patches k in [p_begin, p_end) of a partition of pts[N, >=6] given in CSR form

@@ -133,6 +133,55 @@ def test_G9_reference_field(dev):
     assert rel_rowwise(E, g["E64"]) < TOL
 
 
+def test_reference_field_fused_call_equals_the_two_step_form(dev, monkeypatch):
+    """dnp_reference_field_* (field + tail in one call, round 3) against field_grad followed by the reference's own
+    torch expressions: identical sign decisions and in-place behaviour, normals within rounding; fp32 and fp64, a
+    3-column VIEW of a 6-column tensor (row stride 6), CPU tensors (two-step form), empty source / target sets, and
+    the raw C ABI's argument checks."""
+    lib = _lib.require_device()
+    g = load_golden("G9_reference_field")
+    src, tgt3, tgt6 = t(g["src"]).to(dev), t(g["tgt3"]).to(dev), t(g["tgt6"]).to(dev)
+
+    def two_step(a, b):
+        monkeypatch.setattr(fu, "_reference_field_fused", lambda p, q: None)
+        try:
+            return fu.reference_field(a, b)
+        finally:
+            monkeypatch.undo()
+
+    for dt, tol in ((torch.float32, 2e-6), (torch.float64, 1e-13)):
+        a = src.to(dt)
+        one = fu.reference_field(a, tgt3.to(dt))
+        two = two_step(a, tgt3.to(dt))
+        assert one.shape == (10000, 6) and one.dtype == dt and torch.equal(one[:, :3], two[:, :3])
+        assert float((one[:, 3:] - two[:, 3:]).abs().max()) < tol
+        assert float((one[:, 3:].norm(dim=1) - 1).abs().max()) < 1e-6
+        w1, w2 = tgt6.to(dt).clone(), tgt6.to(dt).clone()
+        r1 = fu.reference_field(a, w1)
+        two_step(a, w2)
+        assert r1.data_ptr() == w1.data_ptr() and torch.equal(w1, w2)
+        view = tgt6.to(dt).clone()
+        got = fu.reference_field(a, view[:, :3])                      # 3-column view, row stride 6
+        assert torch.equal(got, one)
+    assert np.array_equal(fu.reference_field(src, tgt6.clone()).cpu().numpy(), g["out6"])
+    # CPU tensors: staged two-step form, same decisions
+    assert np.array_equal(fu.reference_field(src.cpu(), tgt6.cpu().clone()).numpy(), g["out6"])
+    # empty sets
+    e = fu.reference_field(src[:0], tgt3[:5].clone())
+    assert e.shape == (5, 6) and float(e[:, 3:].abs().max()) == 0
+    keep = tgt6[:5].clone()
+    assert torch.equal(fu.reference_field(src[:0], keep), tgt6[:5])   # zero field: E.n = 0 >= 0 -> nothing flips
+    assert fu.reference_field(src, tgt3[:0].clone()).shape == (0, 6)
+    # C ABI: bad form / missing out are argument errors, not launches
+    ws = torch.empty(lib.dnp_field_grad_workspace_bytes(100, 50, 15000), dtype=torch.uint8, device=dev)
+    args = (_lib.ptr(src), 100, 6, _lib.ptr(tgt6), 50, 6)
+    assert lib.dnp_reference_field_f32(*args, 3, 1e-5, 15000, None, 6, None, _lib.ptr(ws), ws.numel(), _lib.current_stream()) == -1
+    assert lib.dnp_reference_field_f32(*args, 1, 1e-5, 15000, None, 6, None, _lib.ptr(ws), ws.numel(), _lib.current_stream()) == -1
+    assert lib.dnp_reference_field_f32(_lib.ptr(src), 100, 6, _lib.ptr(tgt3), 50, 3, 2, 1e-5, 15000, None, 6, None,
+                                       _lib.ptr(ws), ws.numel(), _lib.current_stream()) == -1
+    assert b"form" in lib.dnp_last_error()
+
+
 def test_G10_edge_weight(dev):
     g = load_golden("G10_edge")
     a, b = t(g["a"]).to(dev), t(g["b"]).to(dev)

@@ -30,9 +30,16 @@ def main():
         if not os.path.exists(path):
             build.build(extra_flags=flags.split(), out=path, verbose=False)
         libs[name] = bind(path)
+    for item in [v for v in os.environ.get("K1_LIBS", "").split(";") if v]:      # ready-made libraries: name=path
+        name, path = item.split("=", 1)
+        libs[name] = bind(path if os.path.isabs(path) else os.path.join(ROOT, path))
     dev = torch.device("cuda:0")
     clouds = {"fandisk": torch.from_numpy(load_golden("G5_fandisk_allpairs")["pc"]).to(dev), "sphere3k": sphere(3000).to(dev),
               "sphere30k": sphere(30000).to(dev), "sphere100k": sphere(100000).to(dev)}
+    from tools.workloads import headline_workload
+    from dipole_normal_prop_amd import util
+    hpc, hpatches, _ = headline_workload()
+    clouds["sorted100k"] = hpc.to(dev)[util.patch_csr(hpatches, dev)[1]].contiguous()   # the bench cloud, sorted by patch
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     only = [c for c in os.environ.get("K1_CLOUDS", "").split(",") if c]
     for cname, pc in clouds.items():
