@@ -671,12 +671,23 @@ def greedy_order_from_interactions(W: np.ndarray, start: int):
     return np.array(order), sigma, np.array(chosen)
 
 
+# Capacity cliffs of the device-side drivers (both have a slower, tested way around them):
+#   * patch greedy loop: one wavefront up to 2048 patches, one workgroup up to dnp_patch_greedy_max_patches() = 16 384
+#     (2.5-2.9 us per step); beyond that the loop runs on the host over a copy of W (greedy_order_from_interactions:
+#     ~20 us per step in numpy plus one P x P device -> host copy).  PATCH_GREEDY_MAX lowers the limit (tests force the
+#     host loop with 0).
+#   * per-point greedy (K4): the persistent kernels hold N < 2^20 points (the index field of their 8-byte granules) and
+#     at most 512 x 20 (fp32) / 512 x 8 (fp64) points per CU; beyond either, _points_stepwise launches one field kernel
+#     and three small torch kernels per step (~140 us per step).  POINT_GREEDY_MAX_PER_GROUP lowers the limit.
+PATCH_GREEDY_MAX = None
+
+
 def _greedy_on_device(W: torch.Tensor, start_t: torch.Tensor):
     """(order[P] int64, sigma[P] fp64, chosen[P-1] fp64) device tensors from the full W[P,P] (fp64, device)."""
     lib = _lib.require_device()
     P = W.shape[0]
     dev = W.device
-    if P > lib.dnp_patch_greedy_max_patches():
+    if P > (lib.dnp_patch_greedy_max_patches() if PATCH_GREEDY_MAX is None else PATCH_GREEDY_MAX):
         order, sigma, chosen = greedy_order_from_interactions(W.cpu().numpy(), int(start_t.item()))
         return (torch.from_numpy(order).to(dev), torch.from_numpy(sigma).to(dev), torch.from_numpy(chosen).to(dev))
     order = torch.empty(P, dtype=torch.int64, device=dev)

@@ -768,6 +768,36 @@ def test_point_propagation_stepwise_fallback_matches_kernel(dev):
     assert torch.equal(a.cpu()[:, 3:], b.cpu()[:, 3:])
 
 
+def test_capacity_cliff_fallbacks_reproduce_the_reference_traces(dev, monkeypatch):
+    """The two capacity cliffs of the device-side drivers (field_utils.PATCH_GREEDY_MAX / POINT_GREEDY_MAX_PER_GROUP):
+    beyond 16 384 patches the greedy loop runs on the host, beyond 2^20 points (or the per-CU register capacity) the
+    per-point driver launches step by step.  Both ways around are forced here on golden cases and must reproduce the
+    reference's complete traces: G6 (72 patches: order, flips, chosen, signs) and G8 (1000 points: the 1000-step order
+    and signs)."""
+    g = load_golden("G6_patch_propagation")
+    tag = "sc_d_w"
+    cloud, patches, allp, diffuse, w = _patch_case(g, tag)
+    monkeypatch.setattr(fu, "PATCH_GREEDY_MAX", 0)                    # as if P exceeded the kernels' 16 384 patches
+    pts = cloud.clone().to(dev)
+    allp_dev = [p.to(dev) for p in allp]
+    fu.strongest_field_propagation(pts, [(i, allp_dev[i]) for i, _ in patches], allp_dev, diffuse=diffuse, weights=w.to(dev))
+    tr = fu.last_trace("patches")
+    assert tr["start"] == int(g[f"order_{tag}"][0]) and np.array_equal(tr["order"], g[f"order_{tag}"])
+    assert np.array_equal((tr["sigma"] < 0)[tr["order"]], g[f"flipped_{tag}"])
+    check_chosen(tr["chosen"], g[f"chosen_{tag}"], f"G6 {tag} host greedy loop")
+    assert np.array_equal(((pts.cpu()[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g[f"sign_{tag}"])
+    monkeypatch.undo()
+
+    g8 = load_golden("G8_point_propagation")
+    monkeypatch.setattr(fu, "POINT_GREEDY_MAX_PER_GROUP", {torch.float32: 0, torch.float64: 0})   # as if N were too large
+    for dflag in ("n", "d"):
+        cloud = t(g8["pc_sub1000"])
+        pts = cloud.clone().to(dev)
+        fu.strongest_field_propagation_points(pts, diffuse=(dflag == "d"), starting_point=0)
+        assert np.array_equal(fu.last_trace("points")["order"], g8[f"order_sub1000_{dflag}"])
+        assert np.array_equal(((pts.cpu()[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g8[f"sign_sub1000_{dflag}"])
+
+
 # ---- BASELINE sizes: size-independent properties -------------------------------------------------------
 def test_sphere100k_all_pairs_properties(dev):
     """BASELINE headline size: linearity is bit exact, a split of the sources adds up, and sampled

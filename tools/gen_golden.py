@@ -808,6 +808,65 @@ def g19(fu, util):
     save("G19_headline_sphere_patch_propagation", **out)
 
 
+def g20(fu, util):
+    """The caller pipelines on data/fandisk.xyz, every stage run by the REFERENCE's own functions (the network vote is
+    skipped: models absent offline) - the fixtures tests/test_callers_gpu.py compares the caller counterparts with,
+    so that no stage of the expected result comes from the product's own helpers:
+      pointcloud: orient_pointcloud.py:14-76 with demos/fandisk.sh's flags (number_parts 30, minimum_points_per_patch
+        100, diffuse): file normals sign-scrambled (seed 3), Transform, _divide_pc + merge_nodes, fix_n_filter (0.0),
+        orient_center, strongest_field_propagation(diffuse), measure_mean_potential flip;
+      large: orient_large.py:18-75 on the unscrambled file: the same prologue, torch.manual_seed(1) randperm
+        representatives (cap 500), strongest_field_propagation_reps(diffuse=True), global flip.
+    Stored: the scramble, the state handed to the propagation (as signs against the input), kept patch ids, start patch,
+    the final normals' signs against the input, the mean potential before the global flip."""
+    import inference_utils_shim as iu
+    raw = load_cloud(util, "fandisk")
+    out = {}
+    for name in ("pointcloud", "large"):
+        cloud = raw.clone()
+        if name == "pointcloud":
+            flip = torch.rand(raw.shape[0], generator=torch.Generator().manual_seed(3)) < 0.5
+            cloud[flip, 3:] *= -1
+            out["scramble"] = flip
+        pc, tr = util.Transform.trans(cloud)
+        allp = ref_patches(util, pc, 30, 100)
+        pc_in = pc.clone()
+        kept = iu.fix_n_filter(pc_in, [p.clone() for p in allp], 0.0)
+        for _, p in kept:
+            pc_in[p] = util.orient_center(pc_in[p])
+        state = pc_in.clone()
+        if name == "pointcloud":
+            pts, calls, inter = _run_patch_driver(fu, util, "patch", pc_in, kept, [p.clone() for p in allp], True, None)
+            firsts = [(int(p[0]), state[int(p[0]), :3]) for p in allp]
+            mins = [(int(p.min()), state[int(p.min()), :3]) for p in allp]
+            order, _ = _order_from_calls(calls, state, firsts, mins)
+        else:
+            torch.manual_seed(1)
+            reps = []
+            for p in allp:
+                perm = torch.randperm(p.shape[0])
+                reps.append((p[perm[:500]], p[perm[500:]]))
+            pts, calls, inter = _run_patch_driver(fu, util, "reps", pc_in, reps, None, True, None)
+            firsts = [(int(r[0]), state[int(r[0]), :3]) for r, _ in reps]
+            mins = [(int(r.min()), state[int(r.min()), :3]) for r, _ in reps]
+            order, _ = _order_from_calls(calls[:len(allp)], state, firsts, mins)
+            out["large_rep_off"] = np.cumsum([0] + [len(r) for r, _ in reps])
+            out["large_rep_idx"] = torch.cat([r for r, _ in reps]).to(torch.int32)
+        phi = fu.measure_mean_potential(pts)
+        if phi < 0:
+            pts[:, 3:] *= -1
+        out[f"{name}_n_patches"] = len(allp)
+        out[f"{name}_kept"] = np.array([i for i, _ in kept])
+        out[f"{name}_state_sign"] = ((state[:, 3:] * cloud[:, 3:]).sum(-1) > 0)
+        out[f"{name}_start"] = int(order[0])
+        out[f"{name}_order"] = order
+        out[f"{name}_mean_potential"] = phi
+        out[f"{name}_final_sign"] = ((pts[:, 3:] * cloud[:, 3:]).sum(-1) > 0)
+        out[f"{name}_final_xyz_head"] = tr.inverse(pts)[:8]
+        print(f"  G20 {name}: {len(kept)}/{len(allp)} patches kept, start {int(order[0])}, mean potential {float(phi):.4e}")
+    save("G20_fandisk_caller_pipelines", **out)
+
+
 def make_inference_shim():
     """inference_utils.py imports models/ (torch_geometric, absent offline) at module level.
     Only its pure-torch fix_n_filter is on the path; load that one function's source object by
@@ -823,7 +882,7 @@ def make_inference_shim():
     spec.loader.exec_module(mod)
 
 
-ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13, G14=g14, G15=g15, G16=g16, GW=gw, GX2=gx2, G17=g17, G18=g18, G19=g19)
+ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13, G14=g14, G15=g15, G16=g16, GW=gw, GX2=gx2, G17=g17, G18=g18, G19=g19, G20=g20)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
