@@ -186,6 +186,7 @@ def main():
         fb = fu._balanced_blocks(sizes, fake)
         p_lo, p_hi = int(fb[0]), int(fb[1])
     my_pairs = float((sizes[p_lo:p_hi] * (N_POINTS - sizes[p_lo:p_hi])).sum())
+    split = fu._pick_source_split(sizes[p_lo:p_hi], N_POINTS)     # the drivers' rule: short launches split their items
 
     # HIP events on the stream the kernels are launched on (torch's current stream = what _lib.current_stream() hands
     # to the C ABI), recorded INSIDE the timed steps: the pair kernel's duration, the interaction kernel's and the
@@ -195,9 +196,9 @@ def main():
             marks[0].record()
         if tiles.fused:              # what the drivers do (field_utils._slabs_and_rows), opened up for the event marks
             w_part = torch.empty((p_hi - p_lo, tiles.n_tiles, 2), dtype=torch.float64, device=dev)
-            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part)
+            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part, split)
         else:
-            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes)
+            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, None, split)
         if marks is not None:
             marks[1].record()
         if tiles.fused:
@@ -251,7 +252,7 @@ def main():
     roofline = {"bound": "valu", "achieved": tflops,
                 "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VALU_PEAK_TFLOPS,
                 "traffic": None, "launch_ms": k_ms, "launch_ms_median": k_med, "launch_ms_min": k_min,
-                "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": launch_pairs,
+                "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": launch_pairs, "source_split": split,
                 "timed": f"HIP events around dnp_patch_fields_tiled_f32 (one pair_kernel_scalar launch) on torch's current "
                          f"stream, recorded inside the {args.steps} timed steps; achieved = 33 flop x pairs_per_launch / "
                          f"mean launch_ms",

@@ -192,14 +192,15 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts, cons
                                const float* patch_box, int64_t p_begin, int64_t p_end, float eps, float* dE,
                                void* stream) {
     return dnp_patch_fields_tiled_f32(pts, N, ld_pts, patch_off, patch_idx, P, point_patch, patch_box, nullptr, p_begin,
-                                      p_end, eps, dE, nullptr, stream);
+                                      p_end, eps, dE, nullptr, 1, stream);
 }
 
 int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
                                const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
                                const float* patch_box, const float* tile_box, int64_t p_begin, int64_t p_end, float eps,
-                               float* dE, double* w_part, void* stream) {
+                               float* dE, double* w_part, int source_split, void* stream) {
     clear_error();
+    DNP_REQUIRE(source_split == 1 || source_split == 4, "source_split=%d (1 or 4)", source_split);
     DNP_REQUIRE(N >= 0 && P >= 0, "negative size");
     DNP_REQUIRE(0 <= p_begin && p_begin <= p_end && p_end <= P, "bad patch range [%lld,%lld) of %lld",
                 (long long)p_begin, (long long)p_end, (long long)P);
@@ -227,16 +228,23 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
         const hipStream_t st = (hipStream_t)stream;
         if (scalar_path) {
             // patch-sorted cloud (what the drivers pass): contiguous sources -> the scalar-unit kernel
-            const dim3 sgrid((unsigned)ceil_div(N, (int64_t)kBlock * kPatchScalarKT), (unsigned)kn);
+            const bool tabled = patch_box && tile_box && kPatchFar && pa.far_d2 > 0.f;
+            const int ss = tabled ? source_split : 1;        // the source split exists for the fully tabled form only
+            const dim3 sgrid((unsigned)ceil_div(N, (int64_t)(kBlock / ss) * kPatchScalarKT), (unsigned)kn);
             pa.chunk_box = patch_box;
             pa.tile_box = tile_box;
             pa.w_part = w_part ? w_part + k0 * ceil_div(N, (int64_t)64 * kPatchScalarKT) * 2 : nullptr;
-            if (patch_box && tile_box && kPatchFar && pa.far_d2 > 0.f && w_part)
-                hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, true>),
-                                   sgrid, dim3(kBlock), 0, st, pa);
-            else if (patch_box && tile_box && kPatchFar && pa.far_d2 > 0.f)
-                hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true>),
-                                   sgrid, dim3(kBlock), 0, st, pa);
+#define DNP_LAUNCH_TABLED(WP, SS)                                                                                        \
+    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, WP, SS>), \
+                       sgrid, dim3(kBlock), 0, st, pa)
+            if (tabled && w_part) {
+                if (ss == 4) DNP_LAUNCH_TABLED(true, 4);
+                else DNP_LAUNCH_TABLED(true, 1);
+            } else if (tabled) {
+                if (ss == 4) DNP_LAUNCH_TABLED(false, 4);
+                else DNP_LAUNCH_TABLED(false, 1);
+            }
+#undef DNP_LAUNCH_TABLED
             else if (patch_box && kPatchFar)
                 hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true>), sgrid,
                                    dim3(kBlock), 0, st, pa);

@@ -499,14 +499,30 @@ __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, cons
 // min / max steps per (wavefront, chunk).  WPART (patch mode, cloud sorted by patch, every tile inside <= 2 groups): the
 // epilogue also leaves sum_t dE[t] . n_t of the tile's targets, split by group (the tile's first group / the other one),
 // in a.w_part - the patch interaction matrix W then needs no second pass over the slabs (dnp_interactions_from_tiles).
+//
+// SS (1, 2, 4): SOURCE SPLIT inside the workgroup.  With SS = 1 the four wavefronts own four target tiles and each runs
+// the whole chunk; with SS = 4 (2) they own one tile (two) and wavefront i runs the chunk's i-th RUN of kRun sources
+// (128 in patch mode), the run terms meet in LDS (fp64) and wavefront 0 adds them IN RUN ORDER and finishes - the same
+// fp32 runs and the same fp64 additions as SS = 1 performs, so the results do not depend on SS, and the SS = 1 code is
+// untouched (a first form that cut chunks at their quarter points cost the SS = 1 path 1 % through nothing but the
+// rewritten loop; profiles/r03_ab_source_split.txt).  Chunks of more than SS runs are evaluated by wavefront 0 alone
+// (the launchers do not pick SS > 1 for those).  A work item is up to SS times shorter, so the end of a launch - when
+// the last items run on a chip that is emptying - shrinks with it, for more workgroups with the same prologue; the
+// launchers use it for SHORT launches only (a rank's share of an 8-way sharded evaluation, small clouds).
 template <typename F, typename PT, int MODE, int KT, int V, bool FAR = false, bool BOX = false, bool TBOX = false,
-          bool WPART = false>
+          bool WPART = false, int SS = 1>
 __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, PT> a) {
     using M = Math<F>;
     constexpr int NC = (MODE == kField) ? 3 : 1;
     constexpr bool kFarPath = FAR && MODE == kField && V == kFast;
+    static_assert(SS == 1 || SS == 2 || SS == 4, "source split: 1, 2 or 4 wavefronts per target tile");
+    static_assert(SS == 1 || MODE == kField, "the source split is built for the field mode");
+    constexpr int kTG = (kBlock / 64) / SS;                 // target tiles per workgroup
     __shared__ F chunk_box[kBlock / 64][6];
+    __shared__ double split_terms[SS > 1 ? SS - 1 : 1][SS > 1 ? kTG : 1][KT][SS > 1 ? NC : 1][SS > 1 ? 64 : 1];
     const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // an SGPR: everything derived from it stays wave-uniform,
+    const int tg = wave / SS, sp = wave % SS;               // above all the source range (scalar loads); tile / source part
     const int64_t chunk = blockIdx.y;
     int64_t s_begin, s_end;
     if (a.chunk_off_dev) {
@@ -516,12 +532,12 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
         s_begin = a.chunk_off[chunk];
         s_end = a.chunk_off[chunk + 1];
     }
-    const int64_t tile_base = (int64_t)blockIdx.x * (kBlock * KT);
+    const int64_t tile_base = (int64_t)blockIdx.x * (kTG * 64 * KT);
     F tx[KT], ty[KT], tz[KT];
     int64_t trow[KT];
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
-        const int64_t t = tile_base + (int64_t)(tid >> 6) * (64 * KT) + k * 64 + (tid & 63);   // a wave owns 64 KT consecutive targets
+        const int64_t t = tile_base + (int64_t)tg * (64 * KT) + k * 64 + (tid & 63);   // a tile = 64 KT consecutive targets
         trow[k] = -1;
         tx[k] = ty[k] = tz[k] = F(0);
         if (t < a.T) {
@@ -554,7 +570,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
         }
         F tlo[3] = {M::kHuge, M::kHuge, M::kHuge}, thi[3] = {-M::kHuge, -M::kHuge, -M::kHuge};
         if constexpr (TBOX) {
-            const int64_t wave_tile = (int64_t)blockIdx.x * (kBlock / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);
+            const int64_t wave_tile = (int64_t)blockIdx.x * kTG + __builtin_amdgcn_readfirstlane(tg);
             const F* tb = a.tile_box + wave_tile * 6;                       // wave-uniform: scalar loads
 #pragma unroll
             for (int c = 0; c < 3; ++c) { tlo[c] = tb[c]; thi[c] = tb[3 + c]; }
@@ -612,10 +628,23 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[k][c] = 0.0;
 
+    // ---- the chunk's runs: kRun sources each from the chunk's start; with SS > 1 (patch mode: kRun = 128) run i of a
+    // chunk of <= SS runs belongs to source part i, longer chunks to part 0 alone ----------------------------------
+    constexpr int kRun = (sizeof(PT) == 4) ? kFlushScalar : kFlush;
     int64_t s = s_begin;                                    // wave-uniform
-    while (s < s_end) {
-        constexpr int kRun = (sizeof(PT) == 4) ? kFlushScalar : kFlush;
-        const int64_t run_end = (s + kRun < s_end) ? s + kRun : s_end;
+    int64_t part_end = s_end;
+    bool exchange = false;                                  // SS > 1: this chunk's runs are spread over the source parts
+    if constexpr (SS > 1) {
+        exchange = (s_end - s_begin) <= (int64_t)SS * kRun;
+        if (exchange) {
+            s = s_begin + (int64_t)sp * kRun;
+            part_end = (s + kRun < s_end) ? s + kRun : s_end;
+        } else if (sp != 0) {
+            s = s_end;                                      // a long chunk: part 0 runs all of it
+        }
+    }
+    while (s < part_end) {
+        const int64_t run_end = (s + kRun < part_end) ? s + kRun : part_end;
         if constexpr (MODE == kField) {
 #if DNP_FAR2
             if (kFarPath && far_chunk == 2) scalar_field_run<F, KT, V, 2>(src, sidx, ld, s, run_end, tx, ty, tz, a.eps, acc);
@@ -650,6 +679,25 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
                                           : (double)(P[0][k] + P[1][k]);
         }
     }
+    if constexpr (SS > 1) {
+        // run i's term travels on its own and part 0 adds the terms in run order: exactly the sums of the SS = 1 form
+        if (exchange && sp != 0) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) split_terms[sp - 1][tg][k][c][tid & 63] = acc[k][c];
+        }
+        __syncthreads();
+        if (sp != 0) return;                                    // wavefront 0 of the tile finishes
+        if (exchange) {
+#pragma unroll
+            for (int q = 1; q < SS; ++q)
+#pragma unroll
+                for (int k = 0; k < KT; ++k)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) acc[k][c] += split_terms[q - 1][tg][k][c][tid & 63];
+        }
+    }
 
     const int64_t chunk_id = a.chunk_base + chunk;
     double w_first = 0.0, w_other = 0.0;                  // WPART: this lane's share of the tile's interaction sums
@@ -660,7 +708,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
     }
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
-        const int64_t t = tile_base + (int64_t)(tid >> 6) * (64 * KT) + k * 64 + (tid & 63);   // a wave owns 64 KT consecutive targets
+        const int64_t t = tile_base + (int64_t)tg * (64 * KT) + k * 64 + (tid & 63);
         if (t < a.T) {
             bool excluded = false;
             int64_t grp = -1;
@@ -702,7 +750,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
             w_other += __shfl_xor(w_other, off, 64);
         }
         const int64_t n_tiles = (a.T + 64 * KT - 1) / (64 * KT);
-        const int64_t wave_tile = (int64_t)blockIdx.x * (kBlock / 64) + (tid >> 6);
+        const int64_t wave_tile = (int64_t)blockIdx.x * kTG + tg;
         if ((tid & 63) == 0 && wave_tile < n_tiles) {
             double* wp = a.w_part + ((int64_t)chunk * n_tiles + wave_tile) * 2;
             wp[0] = w_first;

@@ -557,7 +557,7 @@ def _patch_boxes(work: torch.Tensor, off, idx) -> torch.Tensor:
 
 
 def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, eps: float, boxes=None, tile_boxes=None,
-                 w_part: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 w_part: Optional[torch.Tensor] = None, source_split: int = 1) -> torch.Tensor:
     """dE[p1 - p0, N, 3]: the fields of patches p0..p1 on every point (dnp_patch_fields_tiled_f32).  boxes / tile_boxes:
     the per-cloud box tables of the far-field test (_patch_boxes, _tile_boxes); w_part: receives the per-tile
     interaction partials (see _TileTables)."""
@@ -567,7 +567,8 @@ def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, ep
     with _on_device(work.device):
         rc = lib.dnp_patch_fields_tiled_f32(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
                                             off.shape[0] - 1, _lib.ptr(point_patch), _lib.ptr(boxes), _lib.ptr(tile_boxes),
-                                            p0, p1, float(eps), _lib.ptr(dE), _lib.ptr(w_part), _lib.current_stream())
+                                            p0, p1, float(eps), _lib.ptr(dE), _lib.ptr(w_part), int(source_split),
+                                            _lib.current_stream())
     _lib.check(rc)
     return dE
 
@@ -595,22 +596,39 @@ class _TileTables:
         self.fused = bool(np.all(np.searchsorted(ends, last, side="right") - np.searchsorted(ends, first, side="right") <= 1))
 
 
-def _slabs_and_rows(swork, off, point_patch, b0: int, b1: int, eps: float, boxes, tiles: "_TileTables"):
+# Source split of the pair kernel's work items (include/dnp.h, dnp_patch_fields_tiled_f32): launches below this pair
+# count run with the four wavefronts of a workgroup on ONE target tile, one 128-source run of the patch each.  A launch
+# ends with tens of microseconds of a chip that is emptying, and that tail scales with the item length; shorter items
+# cost more prologues (tools/gpu_item_size.py, profiles/r03_item_size.txt).  Results do not depend on the choice
+# (bit-identical slabs and partials).
+SPLIT4_BELOW_PAIRS = 2.0e9
+
+
+def _pick_source_split(sizes_block: np.ndarray, n_targets: int) -> int:
+    """1 or 4 for a launch over patches of these sizes: 4 only when every patch has 2..4 runs of 128 sources
+    (129..512 points) and the launch is short."""
+    if len(sizes_block) == 0 or int(sizes_block.min()) <= 128 or int(sizes_block.max()) > 512:
+        return 1
+    return 4 if float(sizes_block.sum()) * float(n_targets) < SPLIT4_BELOW_PAIRS else 1
+
+
+def _slabs_and_rows(swork, off, point_patch, b0: int, b1: int, eps: float, boxes, tiles: "_TileTables", sizes=None):
     """One evaluation of patches b0..b1 on the patch-sorted cloud: (dE[b1-b0, N, 3], W rows [b1-b0, P] fp64).  When the
     tiles allow it the interaction rows come out of the pair kernel's epilogue (+ a tiny gather kernel), otherwise from
     the K3 pass over the slabs."""
     P = off.shape[0] - 1
+    split = 1 if (sizes is None or tiles is None or boxes is None) else _pick_source_split(np.asarray(sizes)[b0:b1], swork.shape[0])
     if tiles is not None and tiles.fused and boxes is not None and eps >= 1e-30:
         lib = _lib.require_device()
         K, N = b1 - b0, swork.shape[0]
         w_part = torch.empty((K, tiles.n_tiles, 2), dtype=torch.float64, device=swork.device)
-        dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, tiles.boxes, w_part)
+        dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, tiles.boxes, w_part, split)
         W = torch.empty((K, P), dtype=torch.float64, device=swork.device)
         with _on_device(swork.device):
             _lib.check(lib.dnp_interactions_from_tiles(_lib.ptr(w_part), K, N, _lib.ptr(point_patch), _lib.ptr(off), P,
                                                        _lib.ptr(W), _lib.current_stream()))
         return dE, W
-    dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, None if tiles is None else tiles.boxes)
+    dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, None if tiles is None else tiles.boxes, None, split)
     return dE, _interaction_rows(dE, swork, off, None)
 
 
@@ -821,7 +839,7 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
     W_rows, kept, kept_bytes = [], {}, 0
     for b0 in range(p_lo, p_hi, batch):
         b1 = min(b0 + batch, p_hi)
-        dE, rows = _slabs_and_rows(swork, off, point_patch, b0, b1, eps, boxes, tiles)
+        dE, rows = _slabs_and_rows(swork, off, point_patch, b0, b1, eps, boxes, tiles, sizes)
         W_rows.append(rows)
         # keep this block if it and one more working block still fit
         if want_E and diffuse and kept_bytes + (b1 - b0) * per_slab + (batch * per_slab if b1 < p_hi else 0) <= budget:

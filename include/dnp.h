@@ -166,6 +166,12 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts,
  *     fixed order).  With every tile inside at most two groups (patches of >= R points; rows in no patch last) W follows
  *     from dnp_interactions_from_tiles without a second pass over the 12 N P bytes of slabs; the caller checks that
  *     condition (the drivers do, on the host, from the patch sizes) and uses dnp_interactions_f32 otherwise.
+ * source_split (1 or 4; used with both tables only): with 4 the four wavefronts of a workgroup share ONE target tile and
+ * wavefront i evaluates the patch's i-th run of 128 sources (the run terms meet in LDS and are added in run order):
+ * work items up to four times shorter, for SHORT launches - see profiles/r03_item_size.txt.  dE and w_part do not
+ * depend on source_split (the same fp32 runs, the same fp64 additions); patches of more than 512 points are evaluated
+ * by one wavefront per tile whatever source_split says, patches of <= 128 points are a single run - so 4 pays only
+ * when the patches of the range have 129..512 points (the drivers check that, and use it below 2 10^9 pairs).
  * dE is bit-identical with dnp_patch_fields_boxed_f32's; w_part requires eps >= 1e-30 and both tables.
  */
 int64_t dnp_patch_tile_rows(void);
@@ -174,7 +180,7 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts,
                                const int64_t* patch_off, const int64_t* patch_idx, int64_t P,
                                const int64_t* point_patch, const float* patch_box, const float* tile_box,
                                int64_t p_begin, int64_t p_end, float eps,
-                               float* dE, double* w_part, void* stream);
+                               float* dE, double* w_part, int source_split, void* stream);
 /* W[k][j] = sum of w_part[k][i][slot] over the tiles i that overlap patch j (slot 0 when j is the patch of the tile's
  * first row), in tile order; W is [K, P] doubles.  Same quantity as dnp_interactions_f32 up to fp64 reassociation. */
 int dnp_interactions_from_tiles(const double* w_part, int64_t K, int64_t N, const int64_t* point_patch,

@@ -409,6 +409,51 @@ def test_tile_tables_and_fused_interaction_rows(dev):
     assert float((W[k - 7] - want).abs().max()) <= 1e-6 * float(want.abs().max())
 
 
+def test_source_split_does_not_change_a_bit(dev):
+    """dnp_patch_fields_tiled_f32's source_split = 4 (the four wavefronts of a workgroup on one target tile, one
+    128-source run of the patch each, run terms through LDS, added in run order) against 1: slabs and interaction
+    partials bit-identical - on the headline cloud's patches (all of 129..512 points) and on a cut with patches
+    outside that window (<= 128 points: a single run; > 512: one wavefront evaluates them whatever the split) - and
+    the split-4 slabs agree with the fp64 oracle.  The drivers' rule picks 4 for short launches only."""
+    from tools.workloads import headline_workload
+    pc, patches, _ = headline_workload()
+    off, idx, sizes = util.patch_csr([p.to(dev) for p in patches], dev)
+    swork = pc.to(dev)[idx].contiguous()
+    N, P = swork.shape[0], len(sizes)
+    assert sizes.min() > 128 and sizes.max() <= 512
+    point_patch = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
+    boxes, tiles = fu._patch_boxes(swork, off, None), fu._TileTables(swork, sizes)
+    assert fu._pick_source_split(sizes[:32], N) == 4 and fu._pick_source_split(sizes, N) == 1
+    assert fu._pick_source_split(np.array([100, 300]), N) == 1 and fu._pick_source_split(np.array([300, 600]), N) == 1
+    res = {}
+    for ss in (1, 4):
+        wp = torch.zeros((24, tiles.n_tiles, 2), dtype=torch.float64, device=dev)
+        res[ss] = (fu._patch_slabs(swork, off, None, point_patch, 40, 64, 1e-5, boxes, tiles.boxes, wp, ss), wp)
+    assert torch.equal(res[1][0], res[4][0]) and torch.equal(res[1][1], res[4][1])
+    k = 51
+    others = (point_patch != k).cpu()
+    rows = torch.nonzero(others).flatten()[::53]
+    lo, hi = int(off[k]), int(off[k + 1])
+    ref = c_oracle.field_grad_f64(swork[lo:hi].cpu().numpy(), swork.cpu()[rows].numpy())
+    assert rel_rowwise(res[4][0][k - 40].cpu()[rows], ref) < TOL
+    # patches outside the 2..4-run window, and a ragged last tile
+    sizes2 = np.array([64, 128, 129, 300, 512, 513, 900, 41, 390, 2000], dtype=np.int64)
+    off2 = t(np.concatenate([[0], np.cumsum(sizes2)])).to(dev)
+    n2 = int(sizes2.sum()) + 77                           # 77 rows in no patch at the end
+    sw2 = swork[:n2].contiguous()
+    pp2 = torch.cat([torch.repeat_interleave(torch.arange(len(sizes2), device=dev), off2[1:] - off2[:-1]),
+                     torch.full((77,), -1, dtype=torch.int64, device=dev)])
+    boxes2, tiles2 = fu._patch_boxes(sw2, off2, None), fu._TileTables(sw2, sizes2)
+    a = fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, None, 1)
+    b = fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, None, 4)
+    assert torch.equal(a, b)
+    for k in (1, 2, 5, 9):
+        lo, hi = int(off2[k]), int(off2[k + 1])
+        others = (pp2 != k).cpu()
+        ref = c_oracle.field_grad_f64(sw2[lo:hi].cpu().numpy(), sw2.cpu()[others].numpy())
+        assert rel_rowwise(b[k].cpu()[others], ref) < TOL
+
+
 @pytest.mark.parametrize("eps", [1e-40, 1e-33, 1e-30, 3e-12])
 def test_far_chain_is_safe_for_tiny_eps(dev, eps):
     """Round-2 advisor finding: with a denormal / tiny eps the far-field threshold (eps / 4e-3)^(2/3) admitted pairs whose

@@ -44,6 +44,9 @@ def main():
         if not os.path.exists(path):
             build.build(extra_flags=flags.split(), out=path, verbose=False)
         libs[name] = bind(path)
+    for item in [v for v in os.environ.get("AB_LIBS", "").split(";") if v]:       # ready-made libraries: name=path
+        name, path = item.split("=", 1)
+        libs[name] = bind(path if os.path.isabs(path) else os.path.join(ROOT, path))
     dev = torch.device("cuda:0")
     pc = sphere_cloud()
     patches = fibonacci_patches(pc)
@@ -84,7 +87,7 @@ def main():
             rc = libs[name].dnp_patch_fields_tiled_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch),
                                                        _lib.ptr(boxes), _lib.ptr(tile_boxes), 0, P, 1e-5,
                                                        _lib.ptr(dE[name]), _lib.ptr(w_part) if name == "tiledw" else None,
-                                                       stream)
+                                                       1, stream)
         else:
             rc = libs[name].dnp_patch_fields_boxed_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch),
                                                        _lib.ptr(boxes), 0, P, 1e-5, _lib.ptr(dE[name]), stream)

@@ -52,11 +52,27 @@ def main():
         med, mn = timed(lambda: fu._patch_slabs(pts, off, None, point_patch, 0, K, 1e-5, boxes))
         pairs = float(sizes[:K].sum()) * N
         rows.append((K, med, mn, pairs))
-        print(f"K={K:4d}  {med:.4f}  {mn:.4f}   {pairs / mn / 1e9:.1f} Gpairs/s")
+        print(f"K={K:4d}  {med:.4f}  {mn:.4f}   {pairs / mn / 1e9:.2f} Tpairs/s")
     ks = np.array([r[0] for r in rows], dtype=float)
     mins = np.array([r[2] for r in rows])
     slope, const = np.polyfit(ks[1:], mins[1:], 1)
     print(f"# fit over K >= 32: {slope * 1e3:.2f} us per patch + {const * 1e3:.1f} us per launch")
+
+    print("# source split inside the workgroup (dnp_patch_fields_tiled_f32 source_split): K patches x split, ms median / min")
+    tiles = fu._TileTables(pts, sizes)
+    w_part = torch.empty((P, tiles.n_tiles, 2), dtype=torch.float64, device=dev)
+    ref = fu._patch_slabs(pts, off, None, point_patch, 0, 32, 1e-5, boxes, tiles.boxes, w_part[:32], 1)
+    wref = w_part[:32].clone()
+    for ss in (4,):
+        got = fu._patch_slabs(pts, off, None, point_patch, 0, 32, 1e-5, boxes, tiles.boxes, w_part[:32], ss)
+        print(f"#   split {ss}: slabs bit-identical to split 1: {bool(torch.equal(got, ref))}, partials: {bool(torch.equal(w_part[:32], wref))}")
+    for K in (16, 32, 64, 128, 256):
+        line = f"K={K:4d}"
+        for ss in (1, 4):
+            med, mn = timed(lambda: fu._patch_slabs(pts, off, None, point_patch, 0, K, 1e-5, boxes, tiles.boxes, w_part[:K], ss),
+                            reps=30 if K < 256 else 16)
+            line += f"   split{ss} {med:.4f} / {mn:.4f}"
+        print(line, flush=True)
 
     print("# item size: every patch cut into `split` parts (same pairs, split x the items, 1/split the item length)")
     off_np = off.cpu().numpy()
