@@ -208,10 +208,10 @@ def main():
                 fu._lib.ptr(W), fu._lib.current_stream()))
         else:
             W = fu._interaction_rows(dE, pts, off, idx)
-        if marks is not None:
+        if marks is not None and marks[2] is not None:
             marks[2].record()
         W = parallel.gather_rows(W, bounds)
-        if marks is not None:
+        if marks is not None and marks[2] is not None:
             marks[3].record()
         return W
 
@@ -223,7 +223,12 @@ def main():
 
     for _ in range(args.warmup):
         W = step()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    # every step carries the two marks around the pair kernel; the interaction / all-gather marks only every 4th step at
+    # N = 1 (an event costs a few microseconds of stream time, and there is no collective to watch), every step at N > 1
+    def marks_for(i):
+        detail = world > 1 or i % 4 == 0
+        return [torch.cuda.Event(enable_timing=True) if (j < 2 or detail) else None for j in range(4)]
+    ev = [marks_for(i) for i in range(args.steps)]
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -240,8 +245,8 @@ def main():
 
     # ---- roofline of the dominant kernel, from the events of the timed steps ---------------------------------
     k_all = np.array([m[0].elapsed_time(m[1]) for m in ev])
-    k3_all = np.array([m[1].elapsed_time(m[2]) for m in ev])
-    ag_all = np.array([m[2].elapsed_time(m[3]) for m in ev])
+    k3_all = np.array([m[1].elapsed_time(m[2]) for m in ev if m[2] is not None])
+    ag_all = np.array([m[2].elapsed_time(m[3]) for m in ev if m[2] is not None])
     k_ms, k_med, k_min = float(k_all.mean()), float(np.median(k_all)), float(k_all.min())
     # the launch is part of the step: its mean over the timed steps cannot exceed the mean step of the slowest rank
     assert k_ms <= ms_per_step * 1.0005, f"pair-kernel launch {k_ms:.4f} ms > step {ms_per_step:.4f} ms: timing is inconsistent"

@@ -501,11 +501,11 @@ __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, cons
 // in a.w_part - the patch interaction matrix W then needs no second pass over the slabs (dnp_interactions_from_tiles).
 //
 // SS (1, 2, 4): SOURCE SPLIT inside the workgroup.  With SS = 1 the four wavefronts own four target tiles and each runs
-// the whole chunk; with SS = 4 (2) they own one tile (two) and wavefront i runs the chunk's i-th RUN of kRun sources
-// (128 in patch mode), the run terms meet in LDS (fp64) and wavefront 0 adds them IN RUN ORDER and finishes - the same
-// fp32 runs and the same fp64 additions as SS = 1 performs, so the results do not depend on SS, and the SS = 1 code is
-// untouched (a first form that cut chunks at their quarter points cost the SS = 1 path 1 % through nothing but the
-// rewritten loop; profiles/r03_ab_source_split.txt).  Chunks of more than SS runs are evaluated by wavefront 0 alone
+// the whole chunk; with SS = 4 (2) they own one tile (two) and wavefront i runs the chunk's i-th RUN (see "the chunk's
+// runs" in the kernel), the run terms meet in LDS (fp64) and wavefront 0 adds them IN RUN ORDER and finishes - the same
+// fp32 runs and the same fp64 additions as SS = 1 performs, so the results do not depend on SS, and the SS = 1 loop
+// keeps its form (a first version that rewrote the run loop around quarter cuts cost the SS = 1 path 1 % through
+// nothing but the rewritten loop; profiles/r03_ab_source_split.txt).  Chunks of more than SS runs are evaluated by wavefront 0 alone
 // (the launchers do not pick SS > 1 for those).  A work item is up to SS times shorter, so the end of a launch - when
 // the last items run on a chip that is emptying - shrinks with it, for more workgroups with the same prologue; the
 // launchers use it for SHORT launches only (a rank's share of an 8-way sharded evaluation, small clouds).
@@ -629,22 +629,25 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
         for (int c = 0; c < NC; ++c) acc[k][c] = 0.0;
 
     // ---- the chunk's runs: kRun sources each from the chunk's start; with SS > 1 (patch mode: kRun = 128) run i of a
-    // chunk of <= SS runs belongs to source part i, longer chunks to part 0 alone ----------------------------------
+    // chunk of <= SS runs belongs to source part i, longer chunks to part 0 alone.  (Balanced runs - a 390-source chunk
+    // as 98, 98, 98, 96 instead of 128, 128, 128, 6, so that no wavefront of a split item idles - made the split pay up
+    // to 32 chunks per launch instead of 16 but cost the SS = 1 path 1 %: profiles/r03_ab_source_split.txt.) ----------
     constexpr int kRun = (sizeof(PT) == 4) ? kFlushScalar : kFlush;
+    constexpr int64_t run_len = kRun;
     int64_t s = s_begin;                                    // wave-uniform
     int64_t part_end = s_end;
     bool exchange = false;                                  // SS > 1: this chunk's runs are spread over the source parts
     if constexpr (SS > 1) {
-        exchange = (s_end - s_begin) <= (int64_t)SS * kRun;
+        exchange = (s_end - s_begin) <= (int64_t)SS * run_len;
         if (exchange) {
-            s = s_begin + (int64_t)sp * kRun;
-            part_end = (s + kRun < s_end) ? s + kRun : s_end;
+            s = s_begin + (int64_t)sp * run_len;
+            part_end = (s + run_len < s_end) ? s + run_len : s_end;
         } else if (sp != 0) {
             s = s_end;                                      // a long chunk: part 0 runs all of it
         }
     }
     while (s < part_end) {
-        const int64_t run_end = (s + kRun < part_end) ? s + kRun : part_end;
+        const int64_t run_end = (s + run_len < part_end) ? s + run_len : part_end;
         if constexpr (MODE == kField) {
 #if DNP_FAR2
             if (kFarPath && far_chunk == 2) scalar_field_run<F, KT, V, 2>(src, sidx, ld, s, run_end, tx, ty, tz, a.eps, acc);

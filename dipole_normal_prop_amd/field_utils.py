@@ -599,9 +599,11 @@ class _TileTables:
 # Source split of the pair kernel's work items (include/dnp.h, dnp_patch_fields_tiled_f32): launches below this pair
 # count run with the four wavefronts of a workgroup on ONE target tile, one 128-source run of the patch each.  A launch
 # ends with tens of microseconds of a chip that is emptying, and that tail scales with the item length; shorter items
-# cost more prologues (tools/gpu_item_size.py, profiles/r03_item_size.txt).  Results do not depend on the choice
-# (bit-identical slabs and partials).
-SPLIT4_BELOW_PAIRS = 2.0e9
+# cost more prologues, and with runs of 128 a 390-point patch leaves the fourth wavefront almost idle: measured on the
+# 100 000-point sphere 16 patches per launch 0.350 -> 0.319 ms, 32 patches 0.568 -> 0.586 (tools/gpu_item_size.py,
+# profiles/r03_item_size.txt, r03_ab_source_split.txt).  Results do not depend on the choice (bit-identical slabs
+# and partials).
+SPLIT4_BELOW_PAIRS = 8.0e8
 
 
 def _pick_source_split(sizes_block: np.ndarray, n_targets: int) -> int:

@@ -171,7 +171,7 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts,
  * work items up to four times shorter, for SHORT launches - see profiles/r03_item_size.txt.  dE and w_part do not
  * depend on source_split (the same fp32 runs, the same fp64 additions); patches of more than 512 points are evaluated
  * by one wavefront per tile whatever source_split says, patches of <= 128 points are a single run - so 4 pays only
- * when the patches of the range have 129..512 points (the drivers check that, and use it below 2 10^9 pairs).
+ * when the patches of the range have 129..512 points (the drivers check that, and use it below 8 10^8 pairs).
  * dE is bit-identical with dnp_patch_fields_boxed_f32's; w_part requires eps >= 1e-30 and both tables.
  */
 int64_t dnp_patch_tile_rows(void);

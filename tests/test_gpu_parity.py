@@ -423,7 +423,7 @@ def test_source_split_does_not_change_a_bit(dev):
     assert sizes.min() > 128 and sizes.max() <= 512
     point_patch = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
     boxes, tiles = fu._patch_boxes(swork, off, None), fu._TileTables(swork, sizes)
-    assert fu._pick_source_split(sizes[:32], N) == 4 and fu._pick_source_split(sizes, N) == 1
+    assert fu._pick_source_split(sizes[:16], N) == 4 and fu._pick_source_split(sizes[:32], N) == 1 and fu._pick_source_split(sizes, N) == 1
     assert fu._pick_source_split(np.array([100, 300]), N) == 1 and fu._pick_source_split(np.array([300, 600]), N) == 1
     res = {}
     for ss in (1, 4):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Size sweep of the field / potential entry points (developer tool): time per call and pairs/s."""
 import os, sys, time
+import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -9,14 +10,16 @@ from tools.gpu_check import sphere
 
 dev = torch.device("cuda:0")
 def timeit(fn, reps=20):
-    for _ in range(3): fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps): fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps
+    """median of `reps` synchronised calls after >= 50 ms of warm-up (the clocks drop within milliseconds of idling and
+    the first ~40 ms of work after that run up to 25 % slower; an un-synchronised loop once hid a one-off stall in a mean)"""
+    t_warm = time.perf_counter()
+    while time.perf_counter() - t_warm < 0.05:
+        fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
 
-import numpy as np
 from conftest import load_golden
 grid = fu.util.gen_grid().to(dev)
 fd = torch.from_numpy(load_golden("G5_fandisk_allpairs")["pc"]).to(dev)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # BENCH_BACKEND=gloo rehearsal of bench.py --gpus 2 / 4 on one GPU, then one rank's share of an N-rank run (BENCH_FAKE_WORLD)
-# for N = 1, 2, 4, 8: the evidence under profiles/r02_bench_gloo_rehearsal.txt and profiles/r02_rank_share_timing.txt.
+# for N = 1, 2, 4, 8: the evidence under profiles/r03_bench_gloo_rehearsal.txt and profiles/r03_rank_share_timing.txt.
 set +e
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 OUT=gpurun_out/rehearsal.txt
@@ -13,8 +13,8 @@ done
 S=gpurun_out/rank_share.txt
 : > $S
 for N in 1 2 4 8; do
-  BENCH_FAKE_WORLD=$N timeout -k 10 200 python bench.py --no-cpu-baseline --headline-only --steps 50 --warmup 5 2>/dev/null | grep '^{' | python -c "
+  BENCH_FAKE_WORLD=$N timeout -k 10 200 python bench.py --no-cpu-baseline --headline-only --steps 50 --warmup 10 2>/dev/null | grep '^{' | python -c "
 import json,sys
-b=json.loads(sys.stdin.read()); print($N, round(b['ms_per_step'],4), round(b['roofline']['launch_ms'],4))" >> $S
+b=json.loads(sys.stdin.read()); r=b['roofline']; print($N, round(b['ms_per_step'],4), round(r['launch_ms'],4), round(r['launch_ms_median'],4), round(r['launch_ms_min'],4), r['source_split'], b['step_parts']['interactions_kernel_ms'])" >> $S
 done
 cat $S

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 CSVs under gpurun_out/prof (tools/profile_r02.sh) into the committed summaries
-under profiles/:  <round>_kernel_stats.csv (the --stats table), <round>_pmc_summary.md and
-<round>_pmc_traffic.json (HBM bytes per launch of the dominant kernel, read back by bench.py).
+"""Turn the rocprofv3 CSVs under gpurun_out/prof (tools/profile_bench.sh <round>) into the committed summaries
+under profiles/:  <round>_kernel_stats.csv (per kernel: the --stats figures over ALL dispatches and, from the
+kernel trace, over the STEADY dispatches only - bench.py's 10 warm-up steps run while the clocks ramp and are not
+part of what the bench times), <round>_pmc_summary.md and <round>_pmc_traffic.json (HBM bytes per launch of the
+dominant kernel, read back by bench.py).
+
+    python tools/summarize_prof.py r03 [warmup_steps=10]
 
 HBM bytes follow MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are KB, collected in separate
 --pmc passes; on gfx950 FETCH_SIZE under-reports wide (16 B/lane) streaming reads by exactly 2x and is
@@ -15,7 +19,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+warmup = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -31,8 +36,29 @@ def counters(sub):
     return d
 
 
-shutil.copy(os.path.join(src, "trace", f"{rnd}_kernel_stats.csv"), os.path.join(dst, f"{rnd}_kernel_stats.csv"))
 stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "trace", f"{rnd}_kernel_stats.csv")))}
+# steady-state figures from the per-dispatch trace: a kernel launched once per step drops its first `warmup` dispatches
+import numpy as np  # noqa: E402
+per_kernel = collections.defaultdict(list)
+for r in csv.DictReader(open(os.path.join(src, "trace", f"{rnd}_kernel_trace.csv"))):
+    per_kernel[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+steady = {}
+for name, rows in per_kernel.items():
+    rows.sort()
+    d = np.array([x[1] for x in rows], dtype=np.float64)
+    tail = d[warmup:] if len(d) > 2 * warmup else d
+    steady[name] = (len(tail), float(tail.mean()), float(np.median(tail)), float(tail.min()), float(tail.max()))
+with open(os.path.join(dst, f"{rnd}_kernel_stats.csv"), "w") as f:
+    f.write(f"# rocprofv3 --kernel-trace --stats of bench.py --steps 40 --warmup {warmup} --headline-only; Steady* = without each "
+            f"kernel's first {warmup} dispatches (the bench's untimed warm-up steps)\n")
+    f.write("Name,Calls,AverageNs,MinNs,MaxNs,Percentage,SteadyCalls,SteadyAverageNs,SteadyMedianNs,SteadyMinNs,SteadyMaxNs\n")
+    for name, r in sorted(stats.items(), key=lambda kv: -float(kv[1]["TotalDurationNs"])):
+        sc = steady.get(name, (0, 0, 0, 0, 0))
+        f.write(f'"{name}",{r["Calls"]},{r["AverageNs"]},{r["MinNs"]},{r["MaxNs"]},{r["Percentage"]},{sc[0]},{sc[1]:.0f},{sc[2]:.0f},'
+                f"{sc[3]:.0f},{sc[4]:.0f}\n")
+bl = os.path.join(src, "bench_line_under_rocprof.json")
+if os.path.exists(bl) and os.path.getsize(bl):
+    shutil.copy(bl, os.path.join(dst, f"{rnd}_bench_line_under_rocprof.json"))
 allc = collections.defaultdict(dict)
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
     for k, v in counters(sub).items():
@@ -41,7 +67,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
 
 lines = [f"# {rnd}: rocprofv3 summary of `python bench.py --steps 40 --warmup 10 --no-cpu-baseline --headline-only` (1x MI355X)", "",
          "Per-dispatch averages. Kernel-trace stats and every PMC group come from separate runs "
-         "(tools/profile_r02.sh).", ""]
+         "(tools/profile_bench.sh).  'steady' = without each kernel's first 10 dispatches (bench warm-up).", ""]
 traffic = {}
 for k in sorted(allc, key=lambda n: -float(stats.get(n, {"TotalDurationNs": 0})["TotalDurationNs"])):
     if "dnp::" not in k:
@@ -50,8 +76,10 @@ for k in sorted(allc, key=lambda n: -float(stats.get(n, {"TotalDurationNs": 0})[
     c = allc[k]
     lines.append(f"## `{k[:110]}`")
     if st:
+        sc = steady.get(k)
         lines.append(f"- calls {st['Calls']}, average {float(st['AverageNs']) / 1e3:.1f} us, min {float(st['MinNs']) / 1e3:.1f} us, "
-                     f"{st['Percentage']} % of GPU time")
+                     f"{st['Percentage']} % of GPU time" + (f"; steady ({sc[0]} dispatches): average {sc[1] / 1e3:.1f} us, "
+                                                            f"median {sc[2] / 1e3:.1f} us" if sc else ""))
     if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
         f, w = c.get("FETCH_SIZE", 0.0) * 1024, c.get("WRITE_SIZE", 0.0) * 1024
         lines.append(f"- HBM: FETCH_SIZE {f / 1e6:.1f} MB raw ({2 * f / 1e6:.1f} MB with the gfx950 2x wide-read correction as "
@@ -59,7 +87,8 @@ for k in sorted(allc, key=lambda n: -float(stats.get(n, {"TotalDurationNs": 0})[
         if "pair_kernel" in k and "float, float" in k:
             traffic = {"kernel": k, "fetch_bytes_raw": f, "write_bytes": w, "hbm_bytes_per_launch": f + w,
                        "hbm_bytes_per_launch_upper": 2 * f + w,
-                       "avg_launch_us": float(st["AverageNs"]) / 1e3 if st else None}
+                       "avg_launch_us": float(st["AverageNs"]) / 1e3 if st else None,
+                       "steady_avg_launch_us": steady[k][1] / 1e3 if k in steady else None}
     if "SQ_INSTS_VALU" in c:
         lines.append(f"- SQ: waves {c.get('SQ_WAVES', 0):.0f}, VALU wave-instructions {c['SQ_INSTS_VALU']:.4g}, "
                      f"LDS instructions {c.get('SQ_INSTS_LDS', 0):.4g}, SALU {c.get('SQ_INSTS_SALU', 0):.4g}, "
