@@ -130,6 +130,26 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
         for (size_t i = 0; given < want && i < frac.size(); ++i, ++given) per_leaf[(size_t)frac[i].second] += 1;
     }
 
+    // TAPER (round 3): workgroups are dispatched in chunk order, and a launch ends with every SIMD running its last
+    // wavefront alone, latency bound (the timeline of a fandisk launch, profiles/r03_timeline.txt: workgroups of equal
+    // work live 22 to 84 us, the chip is below half full for the last 35 us of an 85 us launch).  So the chunks of the
+    // LAST leaf of a launch are not equal: the first 60 % of them keep full length, the rest shrink linearly to a
+    // quarter - the last workgroups to start are the shortest, as in longest-processing-time-first scheduling.  Same
+    // number of chunks (same partial slab), the same sums up to the order of the fp64 chunk additions.
+#ifndef DNP_TAPER
+#define DNP_TAPER 1
+#endif
+#ifndef DNP_TAPER_KNEE       // fraction of the chunks that keep full length / relative length of the last chunk
+#define DNP_TAPER_KNEE 0.6
+#endif
+#ifndef DNP_TAPER_MIN
+#define DNP_TAPER_MIN 0.25
+#endif
+    auto taper_weight = [](int64_t i, int64_t m) -> double {      // relative length of chunk i of m
+        const double knee = DNP_TAPER_KNEE * (double)m;
+        if (!DNP_TAPER || m < 8 || (double)i < knee) return 1.0;
+        return 1.0 - (1.0 - DNP_TAPER_MIN) * ((double)i - knee) / ((double)m - knee);
+    };
     Plan::Round cur;
     cur.chunk_off.push_back(0);
     cur.leaf_first.push_back(0);
@@ -148,7 +168,17 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
             cur.chunk_off.push_back((int32_t)lo);
             cur.leaf_first.push_back(0);
         }
-        for (int64_t i = 1; i <= m; ++i) cur.chunk_off.push_back((int32_t)(lo + len * i / m));
+        if (l + 1 == n_leaves) {                     // the launch's tail: tapered chunk lengths
+            double total = 0.0, run = 0.0;
+            for (int64_t i = 0; i < m; ++i) total += taper_weight(i, m);
+            for (int64_t i = 1; i <= m; ++i) {
+                run += taper_weight(i - 1, m);
+                const int64_t cut = (i == m) ? hi : lo + (int64_t)((double)len * run / total);
+                cur.chunk_off.push_back((int32_t)(cut > cur.chunk_off.back() ? cut : cur.chunk_off.back()));
+            }
+        } else {
+            for (int64_t i = 1; i <= m; ++i) cur.chunk_off.push_back((int32_t)(lo + len * i / m));
+        }
         cur.leaf_first.push_back((int32_t)cur.chunk_off.size() - 1);
         lo = hi;
     }
@@ -490,5 +520,9 @@ int dnp_potential_f64(const double* src, int64_t S, int64_t ld_src, const int64_
     return run_pairs<double, kPotential>(src, S, ld_src, src_idx, tgt, T, ld_tgt, tgt_idx, 0.0, max_pts, out, ld_out,
                                          0, 0, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
+
+#ifdef DNP_STAMP
+int dnp_debug_set_stamps_field(void* p) { return dnp::set_stamps_here((unsigned long long*)p) == hipSuccess ? 0 : -4; }
+#endif
 
 }  // extern "C"

@@ -51,6 +51,25 @@
 
 namespace dnp {
 
+#ifdef DNP_STAMP   // timeline builds only (tools/gpu_timeline.py): every workgroup leaves its start / end time (100 MHz
+                   // wall clock) in a buffer set through dnp_debug_set_stamps; the product library has none of this
+static __device__ unsigned long long* g_stamps = nullptr;    // one per translation unit (no relocatable device code)
+static inline hipError_t set_stamps_here(unsigned long long* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p));
+}
+// (nothing stays live across the kernel: a start time kept in registers cost the scalar kernel 17 VGPRs and two waves)
+#define DNP_STAMP_AT(slot)                                                                                \
+    do {                                                                                                  \
+        if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0)   /* a scalar branch: wave 0, every lane the same store */ \
+            g_stamps[2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + (slot)] = wall_clock64();        \
+    } while (0)
+#define DNP_STAMP_BEGIN() DNP_STAMP_AT(0)
+#define DNP_STAMP_END() DNP_STAMP_AT(1)
+#else
+#define DNP_STAMP_BEGIN() do { } while (0)
+#define DNP_STAMP_END() do { } while (0)
+#endif
+
 constexpr int kBlock = 256;       // threads per workgroup (4 waves, one per SIMD)
 #ifndef DNP_FLUSH
 #define DNP_FLUSH 32
@@ -267,6 +286,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
     using M = Math<F>;
     constexpr int NC = (MODE == kField) ? 3 : 1;
     __shared__ __attribute__((aligned(16))) Vec4<F> lds[2][kBlock][2];
+    DNP_STAMP_BEGIN();
 
     const int tid = threadIdx.x;
     const int64_t chunk = blockIdx.y;
@@ -427,6 +447,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
             }
         }
     }
+    DNP_STAMP_END();
 }
 
 // ---- pair_kernel_scalar: sources through the scalar unit (see the header comment); contiguous source rows only
@@ -511,13 +532,18 @@ __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, cons
 // launchers use it for SHORT launches only (a rank's share of an 8-way sharded evaluation, small clouds).
 template <typename F, typename PT, int MODE, int KT, int V, bool FAR = false, bool BOX = false, bool TBOX = false,
           bool WPART = false, int SS = 1>
+#ifdef DNP_STAMP   // the stamps' extra stores tip hipcc's allocation from 61 to 78 VGPRs; the timeline build pins 8 waves per SIMD
+__global__ __launch_bounds__(kBlock, 8) void pair_kernel_scalar(const PairArgs<F, PT> a) {
+#else
 __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, PT> a) {
+#endif
     using M = Math<F>;
     constexpr int NC = (MODE == kField) ? 3 : 1;
     constexpr bool kFarPath = FAR && MODE == kField && V == kFast;
     static_assert(SS == 1 || SS == 2 || SS == 4, "source split: 1, 2 or 4 wavefronts per target tile");
     static_assert(SS == 1 || MODE == kField, "the source split is built for the field mode");
     constexpr int kTG = (kBlock / 64) / SS;                 // target tiles per workgroup
+    DNP_STAMP_BEGIN();
     __shared__ F chunk_box[kBlock / 64][6];
     __shared__ double split_terms[SS > 1 ? SS - 1 : 1][SS > 1 ? kTG : 1][KT][SS > 1 ? NC : 1][SS > 1 ? 64 : 1];
     const int tid = threadIdx.x;
@@ -760,6 +786,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
             wp[1] = w_other;
         }
     }
+    DNP_STAMP_END();
 }
 
 }  // namespace dnp
