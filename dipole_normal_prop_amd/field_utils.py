@@ -573,6 +573,20 @@ def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, ep
     return dE
 
 
+def _tiles_within_two_groups(sizes, n_rows: int, rows_per_tile: int) -> bool:
+    """Does every tile of `rows_per_tile` consecutive rows of the patch-sorted cloud lie inside at most two groups
+    (group = a patch; the rows behind the last patch form one more group)?  From the patch sizes alone (host, no sync):
+    the group index of a tile's last row minus that of its first must be <= 1 (an empty patch in between makes the
+    index jump by two: refused, conservatively)."""
+    n_tiles = -(-n_rows // rows_per_tile)
+    if n_tiles == 0:
+        return True
+    ends = np.cumsum(np.asarray(sizes, dtype=np.int64))
+    first = np.arange(n_tiles, dtype=np.int64) * rows_per_tile
+    last = np.minimum(first + rows_per_tile, n_rows) - 1
+    return bool(np.all(np.searchsorted(ends, last, side="right") - np.searchsorted(ends, first, side="right") <= 1))
+
+
 class _TileTables:
     """Per-cloud tables of the patch-sorted layout for the scalar-unit pair kernel: the boxes of its target tiles
     (tile i = sorted rows [i R, (i+1) R), R = dnp_patch_tile_rows() = the 128 targets one wavefront owns) and whether
@@ -589,11 +603,7 @@ class _TileTables:
         with _on_device(swork.device):
             _lib.check(lib.dnp_tile_boxes_f32(_lib.ptr(swork), N, swork.stride(0), self.rows, _lib.ptr(self.boxes),
                                               _lib.current_stream()))
-        # group of the first and of the last row of every tile, from the patch sizes alone (host, no sync)
-        ends = np.cumsum(np.asarray(sizes, dtype=np.int64))           # rows >= ends[-1]: in no patch = one more group
-        first = np.arange(self.n_tiles, dtype=np.int64) * self.rows
-        last = np.minimum(first + self.rows, N) - 1
-        self.fused = bool(np.all(np.searchsorted(ends, last, side="right") - np.searchsorted(ends, first, side="right") <= 1))
+        self.fused = _tiles_within_two_groups(sizes, N, self.rows)
 
 
 # Source split of the pair kernel's work items (include/dnp.h, dnp_patch_fields_tiled_f32): launches below this pair

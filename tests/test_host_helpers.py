@@ -217,3 +217,28 @@ def test_native_xyz_text_is_python_str_float_byte_for_byte(tmp_path):
     for txt in ("1  2 3\n4 5 6", "1\t2 3\n4 5 6", "1_0 2 3", "1 2 3 4\n1 2 3", "1 2 NaN"):
         assert util._xyz_native(txt, True) is None, txt
     assert np.array_equal(util.xyz2tensor(" +1.5 2 3 \r\n4 5 6\n").numpy()[:, :3], [[1.5, 2, 3], [4, 5, 6]])
+
+
+def test_fused_interaction_rule_and_source_split_policy():
+    """Host-side decisions of the batched drivers (no device involved): when may the pair kernel's epilogue leave the
+    interaction partials (every 128-row tile inside two groups), and which launches split their work items."""
+    from dipole_normal_prop_amd import field_utils as fu
+    assert fu._tiles_within_two_groups([128, 128, 128], 384, 128)
+    assert fu._tiles_within_two_groups([200, 300, 129], 629, 128)
+    assert fu._tiles_within_two_groups([200, 300], 700, 128)             # loose rows behind the last patch: one more group
+    assert not fu._tiles_within_two_groups([100, 20, 300], 420, 128)      # rows 0..127 hold three patches
+    assert not fu._tiles_within_two_groups([130, 0, 130], 260, 128)       # an empty patch: refused (conservative)
+    assert fu._tiles_within_two_groups([], 0, 128) and fu._tiles_within_two_groups([5], 5, 128)
+    # brute force on random cuts
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        sizes = rng.integers(1, 400, rng.integers(1, 12))
+        n = int(sizes.sum()) + int(rng.integers(0, 200))
+        grp = np.concatenate([np.repeat(np.arange(len(sizes)), sizes), np.full(n - int(sizes.sum()), len(sizes))])
+        want = all(len(np.unique(grp[i:i + 128])) <= 2 for i in range(0, n, 128))
+        assert fu._tiles_within_two_groups(sizes, n, 128) == want
+    big = np.full(256, 390)
+    assert fu._pick_source_split(big, 100000) == 1 and fu._pick_source_split(big[:16], 100000) == 4
+    assert fu._pick_source_split(big[:16], 200000) == 1                   # 1.25e9 pairs: above the threshold
+    assert fu._pick_source_split(np.array([128, 300]), 1000) == 1 and fu._pick_source_split(np.array([129, 512]), 1000) == 4
+    assert fu._pick_source_split(np.array([], dtype=np.int64), 1000) == 1
