@@ -221,6 +221,26 @@ def main():
             dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
+    # Clock ramp: after an idle phase the first ~40-60 ms of GPU work run up to 25 % slower (the device climbs to its
+    # sustained clock under load; profiles/r02_kernel_trace_durations.txt, and for an eighth-size step 30 launches after 20
+    # warm-up launches still fall from 0.66 to 0.57 ms).  The W warm-up steps cover that at N = 1 (10 x 4.1 ms); at N ranks a
+    # step is N times shorter, so a fixed number of them does not.  Before the W steps the bench therefore runs untimed
+    # steps until CLOCK_WARMUP_MS of wall time have passed - the same number on every rank (decided by rank 0's clock,
+    # broadcast), outside the timed region, reported on the JSON line.
+    CLOCK_WARMUP_MS = 80.0
+    pre_steps = 0
+    t_pre = time.perf_counter()
+    while True:
+        for _ in range(8):
+            W = step()
+        pre_steps += 8
+        torch.cuda.synchronize()
+        done = torch.tensor([1 if (time.perf_counter() - t_pre) * 1e3 >= CLOCK_WARMUP_MS else 0], dtype=torch.int32,
+                            device=dev if (world > 1 and backend == "nccl") else "cpu")
+        if world > 1:
+            dist.broadcast(done, src=0)
+        if int(done.item()):
+            break
     for _ in range(args.warmup):
         W = step()
     # every step carries the two marks around the pair kernel; the interaction / all-gather marks only every 4th step at
@@ -319,7 +339,9 @@ def main():
     out = None
     if rank == 0:
         out = {"metric": "dipole field-evals/sec (N x N pairs), 100k pts", "value": value, "unit": "pairs/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "clock_warmup": {"ms": CLOCK_WARMUP_MS, "untimed_steps_before_the_warmup_steps": pre_steps},
+               "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
                "config": {"workload": "synthetic 100k-point sphere (seed 1234), 256 Fibonacci patches (whole patches "
