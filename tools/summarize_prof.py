@@ -23,6 +23,15 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 warmup = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
+# the bench line printed under rocprof says how many untimed steps really ran (its clock warm-up + the W warm-up steps)
+_bl = os.path.join(src, "bench_line_under_rocprof.json")
+if len(sys.argv) <= 2 and os.path.exists(_bl) and os.path.getsize(_bl):
+    try:
+        _d = json.load(open(_bl))
+        warmup = int(_d["warmup"]) + int(_d.get("clock_warmup", {}).get("untimed_steps_before_the_warmup_steps", 0))
+    except Exception:
+        pass
+
 os.makedirs(dst, exist_ok=True)
 
 
@@ -49,8 +58,8 @@ for name, rows in per_kernel.items():
     tail = d[warmup:] if len(d) > 2 * warmup else d
     steady[name] = (len(tail), float(tail.mean()), float(np.median(tail)), float(tail.min()), float(tail.max()))
 with open(os.path.join(dst, f"{rnd}_kernel_stats.csv"), "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats of bench.py --steps 40 --warmup {warmup} --headline-only; Steady* = without each "
-            f"kernel's first {warmup} dispatches (the bench's untimed warm-up steps)\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats of bench.py --steps 40 --warmup 10 --headline-only; Steady* = without each "
+            f"kernel's first {warmup} dispatches (the bench's untimed steps: clock warm-up + warm-up steps)\n")
     f.write("Name,Calls,AverageNs,MinNs,MaxNs,Percentage,SteadyCalls,SteadyAverageNs,SteadyMedianNs,SteadyMinNs,SteadyMaxNs\n")
     for name, r in sorted(stats.items(), key=lambda kv: -float(kv[1]["TotalDurationNs"])):
         sc = steady.get(name, (0, 0, 0, 0, 0))
@@ -67,7 +76,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
 
 lines = [f"# {rnd}: rocprofv3 summary of `python bench.py --steps 40 --warmup 10 --no-cpu-baseline --headline-only` (1x MI355X)", "",
          "Per-dispatch averages. Kernel-trace stats and every PMC group come from separate runs "
-         "(tools/profile_bench.sh).  'steady' = without each kernel's first 10 dispatches (bench warm-up).", ""]
+         "(tools/profile_bench.sh).  'steady' = without each kernel's untimed dispatches (the bench's clock warm-up + warm-up steps).", ""]
 traffic = {}
 for k in sorted(allc, key=lambda n: -float(stats.get(n, {"TotalDurationNs": 0})["TotalDurationNs"])):
     if "dnp::" not in k:
