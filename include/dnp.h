@@ -257,7 +257,9 @@ int dnp_patch_pca_f64(const double* pts, int64_t ld_pts, const int64_t* patch_of
  * `remaining` list), sets sigma_j = -1 when I_j < 0 and adds sigma_j W[j] to I.  start is a DEVICE int64
  * (so that a start patch chosen on the device needs no host round trip).  Outputs (device): order[P],
  * sigma[P] (+-1.0), chosen[P-1] (the signed interaction of each chosen patch).  One wavefront up to 2048
- * patches, one workgroup above; P <= dnp_patch_greedy_max_patches() (16384).
+ * patches, one workgroup above; P <= dnp_patch_greedy_max_patches() (16384).  A start outside [0, P) is CLAMPED to
+ * patch 0 (the value lives on the device and is not read back; the Python drivers range-check a host integer start
+ * themselves and raise IndexError).
  */
 int dnp_patch_greedy_max_patches(void);
 int dnp_patch_greedy(const double* W, int64_t P, const int64_t* start, int64_t* order, double* sigma,
