@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define F(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\n"
 #define T(i) "v_rsq_f32 %" #i ", %" #i "\n"
 #define F8 F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
@@ -23,6 +24,8 @@ __global__ void bench(float* out, int iters) {
     const float m = 0.999f, c = 1e-3f;
     f32x4 d0 = {0, 0, 0, 0}, d1 = d0, d2 = d0, d3 = d0;
     float av = a0 * 0.5f, bv = a1 * 0.25f;
+    bf16x8 ab, bb;
+    for (int j = 0; j < 8; ++j) { ab[j] = (__bf16)(a0 + j); bb[j] = (__bf16)(a1 - j); }
     for (int i = 0; i < iters; ++i) {
         if (KIND == 0) {
             asm volatile(PAIR23 PAIR23 PAIR23 PAIR23 PAIR23 PAIR23 PAIR23 PAIR23 OPS);
@@ -33,10 +36,16 @@ __global__ void bench(float* out, int iters) {
                 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, d2, 0, 0, 0);
                 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, d3, 0, 0, 0);
             }
-            if (KIND == 1 || KIND == 3) {
+            if (KIND == 4 || KIND == 5) {       // the same with ONE bf16 16x16x32 MFMA per 16-target block (fp32 split in 3 bf16)
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, d1, 0, 0, 0);
+                d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, d2, 0, 0, 0);
+                d3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, d3, 0, 0, 0);
+            }
+            if (KIND == 1 || KIND == 3 || KIND == 4) {
                 asm volatile(PAIR16 PAIR16 PAIR16 PAIR16 PAIR16 PAIR16 PAIR16 PAIR16 OPS);
             }
-            if (KIND == 1) {   // the chain consumes the MFMA results: tie them in (two adds per step)
+            if (KIND == 1 || KIND == 4) {   // the chain consumes the MFMA results: tie them in (two adds per step)
                 a0 += d0[0] * 1e-30f; a1 += d1[1] * 1e-30f; a2 += d2[2] * 1e-30f; a3 += d3[3] * 1e-30f;
             }
         }
@@ -69,5 +78,7 @@ int main() {
     run<1>("mfma: 4 mfma + 8x(15 fma,rsq)");
     run<2>("mfma_only: 4 mfma");
     run<3>("valu120: 8x(15 fma,rsq)");
+    run<4>("bf16: 4 mfma16x16x32 + 8x(15 fma,rsq)");
+    run<5>("bf16_only: 4 mfma16x16x32");
     return 0;
 }
