@@ -35,3 +35,30 @@ def stats(name, pc, rows_cpu=256):
 stats("G11", _g11_cloud())
 stats("fandisk", torch.from_numpy(load_golden("G5_fandisk_allpairs")["pc"]))
 stats("sphere100k", sphere100k(), rows_cpu=64)
+
+# the bench kernel's slabs against the REFERENCE's own fp32 slabs (G19) and against fp64, every row of three patches
+from dipole_normal_prop_amd import util  # noqa: E402
+from tools.workloads import headline_workload  # noqa: E402
+g19 = load_golden("G19_headline_sphere_patch_propagation")
+pc, patches, _ = headline_workload()
+off, idx, sizes = util.patch_csr([p.to(dev) for p in patches], dev)
+sw = pc.to(dev)[idx].contiguous()
+N, P = sw.shape[0], len(sizes)
+pp = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
+boxes, tiles = fu._patch_boxes(sw, off, None), fu._TileTables(sw, sizes)
+for k in (int(x) for x in g19["slab_patches"]):
+    dE = fu._patch_slabs(sw, off, None, pp, k, k + 1, 1e-5, boxes, tiles.boxes)[0]
+    full = torch.empty_like(dE)
+    full[idx] = dE
+    others = torch.ones(N, dtype=torch.bool)
+    others[patches[k]] = False
+    got = full.cpu()[others].double().numpy()
+    ref32 = g19[f"dE_{k}"].astype(np.float64)
+    ref64 = c_oracle.field_grad_f64(pc[patches[k]].numpy(), pc[others].numpy())
+    nrm = np.linalg.norm(ref64, axis=1)
+    e_ref = np.linalg.norm(got - ref32, axis=1) / nrm
+    e_64 = np.linalg.norm(got - ref64, axis=1) / nrm
+    r_64 = np.linalg.norm(ref32 - ref64, axis=1) / nrm
+    print(f"G19 slab of patch {k:3d} ({len(patches[k])} sources x {int(others.sum())} rows): kernel vs reference fp32 max {e_ref.max():.2e} "
+          f"median {np.median(e_ref):.2e} | kernel vs fp64 max {e_64.max():.2e} median {np.median(e_64):.2e} | reference fp32 vs "
+          f"fp64 max {r_64.max():.2e} median {np.median(r_64):.2e}", flush=True)
