@@ -1130,3 +1130,13 @@ def test_nonfinite_leaf_components_are_counted_and_zeroed(dev, capsys):
     assert lazily == expected, (lazily, expected)
     fu.flush_warnings()
     assert "field_grad" not in capsys.readouterr().out
+
+
+def test_randomised_cross_check_of_the_round3_entry_points(dev):
+    """tools/gpu_fuzz.py for a dozen seconds inside the suite (the tool ran 4253 cases in 200 s without a failure when it
+    was written): random clustered clouds with coincident points, random patch cuts (1 .. 700 points, empty patches, rows in
+    no patch), random eps - slabs bit-identical across tile table / interaction partials / source split, W from the
+    partials against K3, the fused reference_field against the two-step form, field_grad against the fp64 oracle."""
+    from tools import gpu_fuzz
+    cases, fails = gpu_fuzz.run(budget=12.0, seed=20251004)
+    assert cases > 50 and not fails, fails[:5]

@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the round-3 entry points against the fp64 C oracle and against each other, for a time budget
+(default 180 s):  random clouds (clustered, with coincident points), random patch cuts (sizes 1 .. 700, empty patches, rows in
+no patch, ragged last tiles), random eps;
+  * dnp_patch_fields_tiled_f32 with / without the tile table, with / without interaction partials, source_split 1 / 4:
+    slabs bit-identical in every combination, each slab row within 1e-5 of the oracle (rows of cancellation-heavy random
+    clouds get the documented 16 u sum-of-terms allowance),
+  * dnp_interactions_from_tiles against dnp_interactions_f32 where the tiles allow the fused form,
+  * dnp_reference_field_* against field_grad + the torch tail (both forms, fp32 / fp64),
+  * field_grad on ragged shapes against the oracle.
+Prints one line per failure and a summary; exit code 1 on any failure.
+
+    python tools/gpu_fuzz.py [seconds] [seed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dipole_normal_prop_amd import _lib  # noqa: E402
+from dipole_normal_prop_amd import field_utils as fu  # noqa: E402
+from oracle import c_oracle  # noqa: E402
+
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(0)
+
+
+def cloud(n):
+    k = int(rng.integers(1, 12))
+    centres = rng.uniform(-0.5, 0.5, (k, 3))
+    x = centres[rng.integers(0, k, n)] + rng.normal(0, 10.0 ** rng.uniform(-3, -1), (n, 3))
+    if n > 8 and rng.random() < 0.3:                     # some coincident points
+        dup = rng.integers(0, n, max(1, n // 50))
+        x[dup] = x[rng.integers(0, n, len(dup))]
+    nrm = rng.normal(size=(n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return torch.from_numpy(np.concatenate([x, nrm], 1).astype(np.float32))
+
+
+def rel_rows(a, b, allow=None):
+    den = np.linalg.norm(b, axis=-1)
+    den = np.where(den == 0, 1.0, den)
+    err = np.linalg.norm(a - b, axis=-1)
+    if allow is not None:
+        err = np.maximum(err - allow, 0)
+    return float((err / den).max()) if len(den) else 0.0
+
+
+def term_allowance(src, tgt, eps):
+    """16 u * sum over sources of |term|: the documented allowance for cancellation residues."""
+    r = src[None, :, :3].astype(np.float64) - tgt[:, None, :3].astype(np.float64)
+    d = np.linalg.norm(r, axis=-1)
+    mag = 4.0 / (d ** 3 + eps)
+    mag[d == 0] = 0
+    return 16 * 6e-8 * mag.sum(axis=1)
+
+
+def run(budget=180.0, seed=0):
+    """Returns (number of cases, list of failure descriptions)."""
+    global rng
+    rng = np.random.default_rng(seed)
+    fails, cases = [], 0
+    t_end = time.time() + budget
+    while time.time() < t_end:
+        cases += 1
+        kind = cases % 3
+        try:
+            if kind == 0:                                    # patch slabs
+                sizes = []
+                n_p = int(rng.integers(1, 14))
+                for _ in range(n_p):
+                    r = rng.random()
+                    sizes.append(0 if r < 0.05 else int(rng.integers(1, 130)) if r < 0.35 else int(rng.integers(129, 513)) if r < 0.85
+                                 else int(rng.integers(513, 700)))
+                sizes = np.array(sizes, dtype=np.int64)
+                loose = int(rng.integers(0, 200)) if rng.random() < 0.5 else 0
+                N = int(sizes.sum()) + loose
+                if N == 0:
+                    continue
+                pc = cloud(N)
+                sw = pc.to(dev)
+                off_np = np.concatenate([[0], np.cumsum(sizes)])
+                off = torch.from_numpy(off_np).to(dev)
+                pp = torch.cat([torch.repeat_interleave(torch.arange(n_p, device=dev), off[1:] - off[:-1]),
+                                torch.full((loose,), -1, dtype=torch.int64, device=dev)])
+                eps = float(10.0 ** rng.uniform(-7, -4))
+                boxes, tiles = fu._patch_boxes(sw, off, None), fu._TileTables(sw, sizes)
+                base = fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes)
+                wp = {ss: torch.zeros((n_p, tiles.n_tiles, 2), dtype=torch.float64, device=dev) for ss in (1, 4)}
+                variants = {"tile table": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes),
+                            "partials": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, wp[1], 1),
+                            "split 4": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, None, 4),
+                            "split 4 + partials": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, wp[4], 4),
+                            "no boxes": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps)}
+                for name, v in variants.items():
+                    if not torch.equal(v, base):
+                        fails.append(f"case {cases}: slabs differ with '{name}' (sizes {sizes.tolist()}, loose {loose})")
+                if not torch.equal(wp[1], wp[4]):
+                    fails.append(f"case {cases}: partials differ between source_split 1 and 4 (sizes {sizes.tolist()})")
+                if tiles.fused:
+                    W3 = fu._interaction_rows(base, sw, off, None)
+                    Wt = torch.empty_like(W3)
+                    lib = _lib.require_device()
+                    _lib.check(lib.dnp_interactions_from_tiles(_lib.ptr(wp[1]), n_p, N, _lib.ptr(pp), _lib.ptr(off), n_p,
+                                                               _lib.ptr(Wt), _lib.current_stream()))
+                    scale = float(W3.abs().max())
+                    if scale > 0 and float((Wt - W3).abs().max()) > 1e-11 * scale:
+                        fails.append(f"case {cases}: W from tiles differs from K3 by {float((Wt - W3).abs().max()) / scale:.2e}")
+                k = int(rng.integers(0, n_p))
+                if sizes[k] > 0:
+                    others = (pp != k).cpu().numpy()
+                    src = pc[off_np[k]:off_np[k + 1]].numpy()
+                    ref = c_oracle.field_grad_f64(src, pc[others].numpy(), eps=eps)
+                    e = rel_rows(base[k].cpu().numpy()[others].astype(np.float64), ref, term_allowance(src, pc[others].numpy(), eps))
+                    if e > 1e-5:
+                        fails.append(f"case {cases}: slab {k} off by {e:.2e} (sizes {sizes.tolist()}, eps {eps:.1e})")
+                    if float(base[k][off_np[k]:off_np[k + 1]].abs().max()) != 0:
+                        fails.append(f"case {cases}: own rows of slab {k} are not zero")
+            elif kind == 1:                                  # reference_field, fused against two-step
+                S, T = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
+                src, tgt = cloud(S), cloud(T)
+                for dt in (torch.float32, torch.float64):
+                    a = src.to(dev).to(dt)
+                    for cols in (3, 6):
+                        b1 = tgt[:, :cols].contiguous().to(dev).to(dt)
+                        b2 = b1.clone()
+                        one = fu.reference_field(a, b1)
+                        saved = fu._reference_field_fused
+                        fu._reference_field_fused = lambda p, q: None
+                        try:
+                            two = fu.reference_field(a, b2)
+                        finally:
+                            fu._reference_field_fused = saved
+                        if cols == 6:
+                            E = fu.field_grad(a, tgt.to(dev).to(dt))
+                            margin = ((E * tgt[:, 3:].to(dev).to(dt)).sum(-1).abs() / E.norm(dim=1).clamp(min=1e-300)).cpu().numpy()
+                            differ = (one != two).any(dim=1).cpu().numpy()
+                            if differ.any() and margin[differ].max() > 1e-5:
+                                fails.append(f"case {cases}: fused reference_field signs differ at margin {margin[differ].max():.2e} ({dt})")
+                        else:
+                            tol = 5e-6 if dt == torch.float32 else 1e-12
+                            if float((one[:, 3:] - two[:, 3:]).abs().max()) > tol:
+                                fails.append(f"case {cases}: fused reference_field normals off by {float((one[:, 3:] - two[:, 3:]).abs().max()):.2e} ({dt})")
+            else:                                            # plain field_grad on ragged shapes
+                S, T = int(rng.integers(1, 4000)), int(rng.integers(1, 4000))
+                src, tgt = cloud(S), cloud(T)
+                eps = float(10.0 ** rng.uniform(-7, -4))
+                E = fu.field_grad(src.to(dev), tgt.to(dev), eps=eps).cpu().numpy().astype(np.float64)
+                ref = c_oracle.field_grad_f64(src.numpy(), tgt.numpy(), eps=eps)
+                e = rel_rows(E, ref, term_allowance(src.numpy(), tgt.numpy(), eps))
+                if e > 1e-5:
+                    fails.append(f"case {cases}: field_grad {S}x{T} eps {eps:.1e} off by {e:.2e}")
+        except Exception as exc:                             # a library error is a failure too
+            fails.append(f"case {cases} (kind {kind}): {type(exc).__name__}: {exc}")
+        if len(fails) > 20:
+            break
+    fu.flush_warnings()
+    return cases, fails
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 180.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    n_cases, failures = run(budget, seed)
+    for f in failures:
+        print("FAIL", f)
+    print(f"{n_cases} cases in {budget:.0f} s (seed {seed}): {len(failures)} failures")
+    sys.exit(1 if failures else 0)
