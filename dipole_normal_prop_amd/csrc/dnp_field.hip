@@ -69,7 +69,23 @@ static void split_leaves(int64_t lo, int64_t hi, int64_t max_pts, std::vector<in
 // make_plan clips the answer by the shortest chunk it allows and by the by-value chunk table.
 constexpr int64_t kChunkSources = 256, kWantBlocks = 4096, kShortestUseful = 128;
 constexpr size_t kSlabTarget = (size_t)320 << 20;
-static int64_t choose_chunks(int64_t S, int64_t T, int64_t t_tiles, int64_t n_leaves, int nc, bool scalar_kernel) {
+// Source split (round 3, far-field launches of the scalar kernel): the four wavefronts of a workgroup share one target
+// tile and take a quarter of the chunk each, with their own far-field decision - chunks of ~kSplitChunkSources sources
+// then have the item length and the far-test granularity of chunks a quarter as long, and a partial slab a quarter the size.
+#ifndef DNP_K1_SPLIT
+#define DNP_K1_SPLIT 4
+#endif
+#ifndef DNP_K1_SPLIT_CHUNK
+#define DNP_K1_SPLIT_CHUNK 1536
+#endif
+constexpr int64_t kSplitChunkSources = DNP_K1_SPLIT_CHUNK;
+static int64_t choose_chunks(int64_t S, int64_t T, int64_t t_tiles, int64_t n_leaves, int nc, bool scalar_kernel, int split = 1) {
+    if (scalar_kernel && split > 1) {
+        int64_t want = ceil_div(S, kSplitChunkSources);
+        const int64_t slab = (int64_t)(kSlabTarget / ((size_t)(T > 0 ? T : 1) * nc * sizeof(double)));
+        if (want > slab) want = slab;
+        return want < n_leaves ? n_leaves : want;
+    }
     if (!scalar_kernel) {        // LDS kernel (small problems, gathered sources): ~8192 workgroups, the round-1 rule
         const int64_t want = ceil_div((int64_t)8192, t_tiles);
         return want < n_leaves ? n_leaves : want;
@@ -84,7 +100,7 @@ static int64_t choose_chunks(int64_t S, int64_t T, int64_t t_tiles, int64_t n_le
     return want;
 }
 
-static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem, bool scalar_kernel) {
+static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem, bool scalar_kernel, int split = 1) {
     Plan plan;
     const int kKTLarge = scalar_kernel ? kKTScalar : kKTLds;
     std::vector<int64_t> cuts;  // leaf end offsets
@@ -95,13 +111,13 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
 #ifdef DNP_FORCE_KT       // planning experiments only
     plan.kt = DNP_FORCE_KT;
 #endif
-    const int64_t t_tiles = ceil_div(T > 0 ? T : 1, (int64_t)kBlock * plan.kt);
+    const int64_t t_tiles = ceil_div(T > 0 ? T : 1, (int64_t)(kBlock / split) * plan.kt);
     const int64_t n_leaves = (int64_t)cuts.size();
     // chunk cap per round from the slab budget (at least one)
     int64_t cap = (int64_t)(kSlabCap / ((size_t)(T > 0 ? T : 1) * nc * elem));
     if (cap > kMaxChunks) cap = kMaxChunks;
     if (cap < 1) cap = 1;
-    int64_t want = choose_chunks(S, T, t_tiles, n_leaves, nc, scalar_kernel);
+    int64_t want = choose_chunks(S, T, t_tiles, n_leaves, nc, scalar_kernel, split);
 #ifdef DNP_FORCE_CHUNKS   // planning experiments only
     want = DNP_FORCE_CHUNKS;
 #endif
@@ -173,11 +189,16 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
             for (int64_t i = 0; i < m; ++i) total += taper_weight(i, m);
             for (int64_t i = 1; i <= m; ++i) {
                 run += taper_weight(i - 1, m);
-                const int64_t cut = (i == m) ? hi : lo + (int64_t)((double)len * run / total);
+                int64_t cut = (i == m) ? hi : lo + (int64_t)((double)len * run / total);
+                if (split > 1 && i != m) cut = lo + (cut - lo) / (kFlush * split) * (kFlush * split);   // equal parts per wavefront
                 cur.chunk_off.push_back((int32_t)(cut > cur.chunk_off.back() ? cut : cur.chunk_off.back()));
             }
         } else {
-            for (int64_t i = 1; i <= m; ++i) cur.chunk_off.push_back((int32_t)(lo + len * i / m));
+            for (int64_t i = 1; i <= m; ++i) {
+                int64_t cut = lo + len * i / m;
+                if (split > 1 && i != m) cut = lo + (cut - lo) / (kFlush * split) * (kFlush * split);
+                cur.chunk_off.push_back((int32_t)cut);
+            }
         }
         cur.leaf_first.push_back((int32_t)cur.chunk_off.size() - 1);
         lo = hi;
@@ -347,13 +368,17 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
 #define DNP_K1_FAR_FROM 1e9
 #endif
     const bool scalar_kernel = (src_idx == nullptr) && !DNP_K1_FORCE_LDS && (double)S * (double)T >= DNP_K1_SCALAR_FROM;
-    const Plan plan = make_plan(S, T, max_pts, NC, sizeof(double), scalar_kernel);
+    // far-field launches (fp32, >= 10^9 pairs, eps in range) of the scalar kernel split their work items by source
+    const bool far_candidate = sizeof(F) == 4 && DNP_K1_FAR && scalar_kernel && MODE == kField && eps > F(0) &&
+                               (double)S * (double)T >= DNP_K1_FAR_FROM && far_threshold_d2((double)eps) > 0.0;
+    const int split = (far_candidate && T >= (int64_t)kBlock * kKTScalar * kTilesForLarge) ? DNP_K1_SPLIT : 1;
+    const Plan plan = make_plan(S, T, max_pts, NC, sizeof(double), scalar_kernel, split);
     const size_t need = plan_workspace(plan, T, NC, sizeof(double));
     if (!workspace || workspace_bytes < need) {
         set_error("workspace of %zu bytes required, %zu given", need, workspace ? workspace_bytes : (size_t)0);
         return DNP_EWORKSPACE;
     }
-    const int64_t t_tiles = ceil_div(T, (int64_t)kBlock * plan.kt);
+    const int64_t t_tiles = ceil_div(T, (int64_t)(kBlock / split) * plan.kt);
     DNP_REQUIRE(t_tiles <= INT32_MAX, "T too large");
     if (tail != 0 && plan.rounds.size() != 1) {
         set_error("reference_field tail: %zu rounds of chunks (S=%lld, T=%lld) - call dnp_field_grad and finish on the caller's side",
@@ -387,7 +412,12 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
     hipLaunchKernelGGL((pair_kernel<F, double, MODE, KT, V>), grid, dim3(kBlock), 0, stream, pa)
 #define DNP_LAUNCH_SCALAR(KT, V)                                                                                  \
     do {                                                                                                          \
-        if (sizeof(F) == 4 && DNP_K1_FAR && pa.far_d2 > F(0))                                                     \
+        if (sizeof(F) == 4 && DNP_K1_FAR && pa.far_d2 > F(0) && split == 4 && KT == kKTScalar && V == kFast &&   \
+            MODE == kField)                                                                                       \
+            hipLaunchKernelGGL((pair_kernel_scalar<F, double, kField, kKTScalar, kFast, (sizeof(F) == 4 && DNP_K1_FAR), \
+                                                   false, false, false, (sizeof(F) == 4 && DNP_K1_FAR) ? 4 : 1>),  \
+                               grid, dim3(kBlock), 0, stream, pa);                                                \
+        else if (sizeof(F) == 4 && DNP_K1_FAR && pa.far_d2 > F(0))                                                \
             hipLaunchKernelGGL((pair_kernel_scalar<F, double, MODE, KT, V, (sizeof(F) == 4 && DNP_K1_FAR)>), grid, \
                                dim3(kBlock), 0, stream, pa);                                                      \
         else                                                                                                      \

@@ -577,11 +577,35 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
     const int64_t* __restrict__ sidx = a.src_idx;
     const int64_t ld = a.ld_src;
 
+    // SS > 1 with fp64 partial slabs (the generic entry points): the chunk is cut into SS contiguous PARTS of equal
+    // length (a multiple of kFlush), wavefront sp takes part sp WITH ITS OWN far-field decision from its own part's box -
+    // a chunk can then be SS times longer (a partial slab SS times smaller) at the same item length and the same
+    // granularity of the far test.  (fp32 slabs, patch mode: run i of the chunk to wavefront i, see further down.)
+    constexpr bool kParts = SS > 1 && sizeof(PT) == 8;
+    int64_t part_lo = s_begin, part_hi = s_end;
+    if constexpr (kParts) {
+        const int64_t len = s_end - s_begin;
+        const int64_t part = ((len + SS - 1) / SS + kFlush - 1) / kFlush * kFlush;
+        part_lo = s_begin + (int64_t)sp * part;
+        part_lo = part_lo < s_end ? part_lo : s_end;
+        part_hi = part_lo + part < s_end ? part_lo + part : s_end;
+    }
+
     int far_chunk = 0;
     if (kFarPath && a.far_d2 > F(0)) {     // far_d2 <= 0: the launcher switched the far machinery off (small problems)
         // box of the chunk's sources (given, or found by the workgroup) and of this wave's targets
         constexpr bool given = BOX;          // a compile-time choice: a run-time branch here cost 19 VGPRs (occupancy 8 -> 6)
-        if constexpr (!given) {
+        static_assert(!(kParts && BOX), "source parts find their own boxes");
+        F plo[3] = {M::kHuge, M::kHuge, M::kHuge}, phi[3] = {-M::kHuge, -M::kHuge, -M::kHuge};   // kParts: this part's box
+        if constexpr (kParts) {
+            for (int64_t q = part_lo + (tid & 63); q < part_hi; q += 64) {
+                const F* p = src + q * ld;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { plo[c] = p[c] < plo[c] ? p[c] : plo[c]; phi[c] = p[c] > phi[c] ? p[c] : phi[c]; }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { plo[c] = wave_min<F>(plo[c]); phi[c] = wave_max<F>(phi[c]); }
+        } else if constexpr (!given) {
             F lo[3] = {M::kHuge, M::kHuge, M::kHuge}, hi[3] = {-M::kHuge, -M::kHuge, -M::kHuge};
             for (int64_t q = s_begin + tid; q < s_end; q += kBlock) {
                 const F* p = src + (sidx ? sidx[q] : q) * ld;
@@ -612,7 +636,16 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
             for (int c = 0; c < 3; ++c) { tlo[c] = wave_min<F>(tlo[c]); thi[c] = wave_max<F>(thi[c]); }
         }
         F d2box = F(0);
-        if constexpr (given) {
+        if constexpr (kParts) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                F gap = plo[c] - thi[c];
+                const F gap2 = tlo[c] - phi[c];
+                gap = gap2 > gap ? gap2 : gap;
+                gap = gap > F(0) ? gap : F(0);
+                d2box = M::fma(gap, gap, d2box);
+            }
+        } else if constexpr (given) {
             const F* b = a.chunk_box + (a.chunk_base + chunk) * 6;          // wave-uniform: scalar loads
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -663,7 +696,11 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
     int64_t s = s_begin;                                    // wave-uniform
     int64_t part_end = s_end;
     bool exchange = false;                                  // SS > 1: this chunk's runs are spread over the source parts
-    if constexpr (SS > 1) {
+    if constexpr (kParts) {
+        exchange = true;
+        s = part_lo;
+        part_end = part_hi;
+    } else if constexpr (SS > 1) {
         exchange = (s_end - s_begin) <= (int64_t)SS * run_len;
         if (exchange) {
             s = s_begin + (int64_t)sp * run_len;
