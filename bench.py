@@ -7,17 +7,24 @@ synthetic sphere of BASELINE.json (config 4: 256 patches), one process per GPU.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A STEP is one pass of the data-parallel hot path over the cloud: every one of the 256 per-patch
-field evaluations `field_grad(pts[patch_k], pts[~patch_k])` (dnp_patch_fields_f32 - all of them in
-one launch per rank), the patch interaction matrix rows (dnp_interactions_f32) and, for N > 1, the
-RCCL all-gather of those rows that hands rank 0 everything the sequential greedy loop needs.
+field evaluations `field_grad(pts[patch_k], pts[~patch_k])` (dnp_patch_fields_tiled_f32 - all of them in
+one launch per rank, the per-tile interaction partials out of the same kernel's epilogue), the patch
+interaction matrix rows (dnp_interactions_from_tiles) and, for N > 1, the RCCL all-gather of those rows
+that hands rank 0 everything the sequential greedy loop needs - exactly what the drivers do
+(field_utils._slabs_and_rows).  After the timed steps the gathered matrix is run through the device
+greedy loop and compared with the REFERENCE's own trace on this cloud (tests/golden/G19).
 Patches are sharded over the ranks in contiguous size-balanced blocks, so the total work is fixed
 as N grows ("strong").  Inputs are resident in HBM before the timed region.  `value` counts the
 algorithmic pairs sum_k |patch_k| * (N - |patch_k|) of all ranks per second of the slowest rank.
 
 Also printed on the same JSON line:
   roofline      the pair kernel against the FP32 vector-ALU roofline that binds it (33 flop/pair,
-                DESIGN.md), timed live with HIP events around the launch; `hbm` carries the
-                algorithmic HBM GB/s the metric name asks for (<< 1 % of 8 TB/s by construction).
+                DESIGN.md), timed by HIP events recorded INSIDE the timed steps (mean / median / min;
+                launch_ms <= ms_per_step is asserted); `hbm` carries the algorithmic HBM GB/s the metric
+                name asks for (<< 1 % of 8 TB/s by construction).
+  step_parts    pair kernel / interaction kernel / all-gather times of a step; per_rank at N > 1.
+  clock_warmup  the untimed steps run before the W warm-up steps (80 ms of load: a device climbs to its
+                sustained clock in ~50 ms, and at N ranks a step is N times shorter).
   cpu_baseline  the oracle's dense-broadcast PyTorch port of the reference path, timed on this
                 box's host cores on a bounded sample (rank 0, N = 1 only).
 """
