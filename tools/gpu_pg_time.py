@@ -26,7 +26,8 @@ dev = torch.device("cuda:0")
 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 g = torch.Generator().manual_seed(1)
 for P in (72, 256, 512, 1024, 2048, 4096, 8192, 16384):
-    W = torch.randn(P, P, generator=g, dtype=torch.float64).to(dev)
+    W0 = torch.randn(P, P, generator=g, dtype=torch.float64).to(dev)
+    W = torch.empty_like(W0)
     start = torch.zeros(1, dtype=torch.int64, device=dev)
     res = {}
     for name, lib in libs.items():
@@ -34,6 +35,7 @@ for P in (72, 256, 512, 1024, 2048, 4096, 8192, 16384):
         chosen = torch.empty(P, dtype=torch.float64, device=dev)
         ts = []
         for _ in range(4):
+            W.copy_(W0)            # W freshly written by other CUs, as in the drivers (not warm in the greedy CU's caches)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             rc = lib.dnp_patch_greedy(_lib.ptr(W), P, _lib.ptr(start), _lib.ptr(order), _lib.ptr(sigma), _lib.ptr(chosen), stream)
