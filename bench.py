@@ -235,7 +235,10 @@ def main():
     # steps until CLOCK_WARMUP_MS of wall time have passed - the same number on every rank (decided by rank 0's clock,
     # broadcast), outside the timed region, reported on the JSON line.
     CLOCK_WARMUP_MS = 80.0
-    pre_steps = 0
+    for _ in range(8):             # absorbs lazy initialisation (RCCL communicator, allocator, code objects): not load
+        W = step()
+    fence()
+    pre_steps = 8
     t_pre = time.perf_counter()
     while True:
         for _ in range(8):
