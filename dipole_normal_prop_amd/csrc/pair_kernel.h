@@ -620,7 +620,12 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
         }
         F tlo[3] = {M::kHuge, M::kHuge, M::kHuge}, thi[3] = {-M::kHuge, -M::kHuge, -M::kHuge};
         if constexpr (TBOX) {
-            const int64_t wave_tile = (int64_t)blockIdx.x * kTG + __builtin_amdgcn_readfirstlane(tg);
+            // (the last workgroup's wavefronts may lie past the last tile: they have no targets, but the table has no
+            // entry for them either - round 3's first form read up to 72 bytes past its end, found by tools/gpu_fuzz.py
+            // as a memory access fault when the table ended on a page boundary)
+            const int64_t n_tiles = (a.T + 64 * KT - 1) / (64 * KT);
+            int64_t wave_tile = (int64_t)blockIdx.x * kTG + __builtin_amdgcn_readfirstlane(tg);
+            wave_tile = wave_tile < n_tiles ? wave_tile : n_tiles - 1;
             const F* tb = a.tile_box + wave_tile * 6;                       // wave-uniform: scalar loads
 #pragma unroll
             for (int c = 0; c < 3; ++c) { tlo[c] = tb[c]; thi[c] = tb[3 + c]; }
