@@ -7,7 +7,10 @@ no patch, ragged last tiles), random eps;
     clouds get the documented 16 u sum-of-terms allowance),
   * dnp_interactions_from_tiles against dnp_interactions_f32 where the tiles allow the fused form,
   * dnp_reference_field_* against field_grad + the torch tail (both forms, fp32 / fp64),
-  * field_grad on ragged shapes against the oracle.
+  * field_grad on ragged shapes against the oracle,
+  * every 40th case one of the heavier kinds: field_grad / reference_field at 4 10^8 .. 2.7 10^9 pairs (scalar kernel, far
+    launches, source split), the patch driver against the oracle's driver (visit order, normals), potential on ragged
+    shapes, the per-point driver in both forms.
 Prints one line per failure and a summary; exit code 1 on any failure.
 
     python tools/gpu_fuzz.py [seconds] [seed]
@@ -67,7 +70,7 @@ def run(budget=180.0, seed=0):
     t_end = time.time() + budget
     while time.time() < t_end:
         cases += 1
-        kind = cases % 3
+        kind = cases % 3 if cases % 40 else 3 + (cases // 40) % 4      # every 40th case: one of the heavier kinds
         try:
             if kind == 0:                                    # patch slabs
                 sizes = []
@@ -154,6 +157,69 @@ def run(budget=180.0, seed=0):
                 e = rel_rows(E, ref, term_allowance(src.numpy(), tgt.numpy(), eps))
                 if e > 1e-5:
                     fails.append(f"case {cases}: field_grad {S}x{T} eps {eps:.1e} off by {e:.2e}")
+            if kind == 3:                                    # field_grad around / above 10^9 pairs (scalar kernel, far launches, source split)
+                S, T = int(rng.integers(20000, 52000)), int(rng.integers(20000, 52000))
+                src, tgt = cloud(S), cloud(T)
+                if rng.random() < 0.5:                       # spatially sorted: the far chains are really taken
+                    src = src[np.argsort(np.floor((src[:, 0].numpy() + 1) * 16) * 1024 + np.floor((src[:, 1].numpy() + 1) * 16))]
+                    tgt = tgt[np.argsort(np.floor((tgt[:, 0].numpy() + 1) * 16) * 1024 + np.floor((tgt[:, 1].numpy() + 1) * 16))]
+                eps = float(10.0 ** rng.uniform(-6, -4))
+                E = fu.field_grad(src.to(dev), tgt.to(dev), eps=eps).cpu().numpy().astype(np.float64)
+                rows = rng.choice(T, 96, replace=False)
+                ref = c_oracle.field_grad_f64(src.numpy(), tgt.numpy()[rows], eps=eps)
+                e = rel_rows(E[rows], ref, term_allowance(src.numpy(), tgt.numpy()[rows], eps))
+                if e > 1e-5 or not np.isfinite(E).all():
+                    fails.append(f"case {cases}: field_grad {S}x{T} (large) eps {eps:.1e} off by {e:.2e}")
+                out = fu.reference_field(src.to(dev), tgt[:, :3].contiguous().to(dev))     # the fused tail on a large call
+                nrm = ref / np.linalg.norm(ref, axis=1, keepdims=True)
+                if eps == 1e-5 and np.abs(out.cpu().numpy()[rows, 3:] - nrm).max() > 1e-4:
+                    fails.append(f"case {cases}: reference_field {S}x{T} normals off")
+            elif kind == 4:                                  # the patch driver against the oracle's driver
+                from oracle import dipole_oracle as O
+                n_p = int(rng.integers(2, 9))
+                sizes = rng.integers(20, 260, n_p)
+                N = int(sizes.sum())
+                pc = cloud(N)
+                cuts = np.concatenate([[0], np.cumsum(sizes)])
+                perm = rng.permutation(N)
+                patches = [torch.from_numpy(np.sort(perm[cuts[k]:cuts[k + 1]])) for k in range(n_p)]
+                diffuse = bool(rng.integers(0, 2))
+                start = int(rng.integers(0, n_p))
+                a = pc.clone().to(dev)
+                fu.strongest_field_propagation(a, [(i, p.to(dev)) for i, p in enumerate(patches)], [p.to(dev) for p in patches],
+                                               diffuse=diffuse, start_patch=start)
+                tr = fu.last_trace("patches")
+                ref, rtr = O.strongest_field_propagation(pc.clone(), list(enumerate(patches)), patches, diffuse=diffuse, start_patch=start)
+                if not np.array_equal(tr["order"], rtr["order"]):
+                    # a different order is a failure only when the oracle's own decision was not a near-tie
+                    ch = np.abs(np.asarray(rtr["chosen"], dtype=np.float64))
+                    fails.append(f"case {cases}: patch driver order differs (P={n_p}, N={N}, diffuse={diffuse}, min |chosen| {ch.min():.3e})")
+                elif not diffuse and not torch.equal(a.cpu()[:, 3:], ref[:, 3:]):
+                    fails.append(f"case {cases}: patch driver normals differ (P={n_p}, N={N})")
+            elif kind == 5:                                  # potential on ragged shapes
+                S, T = int(rng.integers(1, 5000)), int(rng.integers(1, 3000))
+                src, tgt = cloud(S), cloud(T)
+                tgt[:, :3] += 0.37                            # keep targets off the sources: the potential has no eps
+                phi = fu.potential(src.to(dev), tgt.to(dev)).cpu().numpy().astype(np.float64)
+                ref = c_oracle.potential_f64(src.numpy(), tgt.numpy())
+                if np.abs(phi - ref).max() > 1e-5 * max(np.abs(ref).max(), 1e-30):
+                    fails.append(f"case {cases}: potential {S}x{T} off by {np.abs(phi - ref).max() / np.abs(ref).max():.2e}")
+            elif kind == 6:                                  # per-point driver, both forms: a complete visit order, forms agree
+                N = int(rng.integers(2, 260))
+                pc = cloud(N)
+                outs = []
+                for form in (1, 2):
+                    fu.POINT_GREEDY_FORM = form
+                    try:
+                        b = pc.clone().to(dev)
+                        fu.strongest_field_propagation_points(b, diffuse=True, starting_point=0)
+                    finally:
+                        fu.POINT_GREEDY_FORM = 0
+                    if sorted(fu.last_trace("points")["order"].tolist()) != list(range(N)):
+                        fails.append(f"case {cases}: per-point order is not a permutation (N={N}, form {form})")
+                    outs.append((b.cpu(), fu.last_trace("points")["order"].copy()))
+                if not (torch.equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])):
+                    fails.append(f"case {cases}: the two per-point forms disagree (N={N})")
         except Exception as exc:                             # a library error is a failure too
             fails.append(f"case {cases} (kind {kind}): {type(exc).__name__}: {exc}")
         if len(fails) > 20:
