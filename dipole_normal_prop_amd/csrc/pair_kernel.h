@@ -191,12 +191,15 @@ __device__ __forceinline__ void pair_field(F sx, F sy, F sz, F px, F py, F pz, F
 // Far-field chain (eps > 0, every pair of the wave farther apart than far_d2 = (eps / kFarRatio)^(2/3), i.e.
 // e = eps / |r|^3 < kFarRatio): ONE transcendental instead of two.
 //   u = rsq(d2); u3 = u^3 = 1/|r|^3;  w = 1/(|r|^3 + eps) = u3 / (1 + e) = u3 (1 - e + e^2 - ...),  e = eps u3
-// truncated after e^2: relative error e^3 < kFarRatio^3 = 6.4e-8, one fp32 ulp, for the nearest far pairs and falling
-// with |r|^-9 (kFarRatio 2e-3 -> 4e-3: 1.3 % faster, error of the summed slabs against fp64 unchanged).  22 full-rate + 1
+// truncated after e^2: relative error e^3 < kFarRatio^3 = 5.1e-7 for the nearest far pairs and falling with |r|^-9
+// (kFarRatio 2e-3 -> 4e-3 in round 2: 1.3 % faster; 4e-3 -> 8e-3 in round 3: another 0.9 %, 4.081 against 4.120 ms
+// same-box; the error of the summed slabs against fp64 unchanged both times at 1.9e-8 median / 5.8e-8 max, a slab row
+// at the threshold distance carries up to 5e-7 of systematic error - the bound is 1e-5; 1.2e-2 would give 1.2 % for
+// 1.7e-6: profiles/r03_ab_far_ratio.txt).  22 full-rate + 1
 // quarter-rate instructions against 19 + 2 for the exact chain (a transcendental costs ~13 issue cycles when
 // mixed with FMAs).  No coincident pair can be in a far tile.
 #ifndef DNP_FAR_RATIO
-#define DNP_FAR_RATIO 4e-3
+#define DNP_FAR_RATIO 8e-3
 #endif
 constexpr double kFarRatio = DNP_FAR_RATIO;
 // Host side: the squared box distance from which the far chains run; 0 switches them off.  They need a normal-range
@@ -678,8 +681,11 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
             }
         }
 #if DNP_FAR2
-        static_assert(kFarRatio == 4e-3 && kFar2Ratio == 2.4e-4, "kFar2Scale below is (kFarRatio / kFar2Ratio)^(2/3)");
-        constexpr F kFar2Scale = (F)6.5242;     // (4e-3 / 2.4e-4)^(2/3)
+#ifndef DNP_FAR2_SCALE   // (kFarRatio / kFar2Ratio)^(2/3); A/B builds that move DNP_FAR_RATIO pass the matching value
+#define DNP_FAR2_SCALE 10.357
+        static_assert(kFarRatio == 8e-3 && kFar2Ratio == 2.4e-4, "DNP_FAR2_SCALE is (kFarRatio / kFar2Ratio)^(2/3) = 10.357 for these");
+#endif
+        constexpr F kFar2Scale = (F)DNP_FAR2_SCALE;
         far_chunk = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2) + (int)(d2box > a.far_d2 * kFar2Scale));
 #else
         far_chunk = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2));
