@@ -231,12 +231,14 @@ __device__ __forceinline__ void pair_field_far(F sx, F sy, F sz, F px, F py, F p
     bz = M::fma(w, pz, bz);
 }
 
-// Second tier (e = eps / |r|^3 < kFar2Ratio = 2.4e-4): the e^2 term is below one fp32 ulp too - w = u3 (1 - e), one
-// instruction less (22 full-rate + 1 transcendental).
+// Second tier (e = eps / |r|^3 < kFar2Ratio): the e^2 term is dropped as well - w = u3 (1 - e), one instruction less
+// (21 full-rate + 1 transcendental).  kFar2Ratio was 2.4e-4 in round 2 (e^2 below one fp32 ulp); round 3 put it at 7e-4,
+// where the dropped e^2 <= 4.9e-7 matches the first tier's e^3 <= 5.1e-7: 4.070 against 4.131 ms same-box (-1.5 %),
+// summed-slab error against fp64 unchanged (profiles/r03_ab_far_ratio.txt; 1e-3 would give -1.8 % for e^2 <= 1e-6).
 #ifndef DNP_FAR2      // 1: second tier on (4.187 -> 4.096 ms per launch on the bench workload, summed-slab accuracy unchanged)
 #define DNP_FAR2 1
 #endif
-constexpr double kFar2Ratio = 2.4e-4;
+constexpr double kFar2Ratio = 7e-4;
 template <typename F>
 __device__ __forceinline__ void pair_field_far2(F sx, F sy, F sz, F px, F py, F pz, F tx, F ty, F tz, F eps,
                                                 F& ax, F& ay, F& az, F& bx, F& by, F& bz) {
@@ -682,8 +684,8 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
         }
 #if DNP_FAR2
 #ifndef DNP_FAR2_SCALE   // (kFarRatio / kFar2Ratio)^(2/3); A/B builds that move DNP_FAR_RATIO pass the matching value
-#define DNP_FAR2_SCALE 10.357
-        static_assert(kFarRatio == 8e-3 && kFar2Ratio == 2.4e-4, "DNP_FAR2_SCALE is (kFarRatio / kFar2Ratio)^(2/3) = 10.357 for these");
+#define DNP_FAR2_SCALE 5.0736
+        static_assert(kFarRatio == 8e-3 && kFar2Ratio == 7e-4, "DNP_FAR2_SCALE is (kFarRatio / kFar2Ratio)^(2/3) = 5.0736 for these");
 #endif
         constexpr F kFar2Scale = (F)DNP_FAR2_SCALE;
         far_chunk = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2) + (int)(d2box > a.far_d2 * kFar2Scale));
