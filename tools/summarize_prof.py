@@ -55,7 +55,7 @@ steady = {}
 for name, rows in per_kernel.items():
     rows.sort()
     d = np.array([x[1] for x in rows], dtype=np.float64)
-    tail = d[warmup:] if len(d) > 2 * warmup else d
+    tail = d[warmup:] if len(d) > warmup else d
     steady[name] = (len(tail), float(tail.mean()), float(np.median(tail)), float(tail.min()), float(tail.max()))
 with open(os.path.join(dst, f"{rnd}_kernel_stats.csv"), "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats of bench.py --steps 40 --warmup 10 --headline-only; Steady* = without each "
