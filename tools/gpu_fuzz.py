@@ -68,7 +68,11 @@ def run(budget=180.0, seed=0):
     rng = np.random.default_rng(seed)
     fails, cases = [], 0
     t_end = time.time() + budget
+    t_note = time.time() + 60.0
     while time.time() < t_end:
+        if time.time() > t_note:                             # a sign of life once a minute (long runs under gpurun)
+            print(f"  ... {cases} cases, {len(fails)} failures", flush=True)
+            t_note = time.time() + 60.0
         cases += 1
         kind = cases % 3 if cases % 40 else 3 + (cases // 40) % 4      # every 40th case: one of the heavier kinds
         try:
