@@ -19,6 +19,10 @@ constexpr int kPatchScalarKT = 2;         // scalar kernel (patch-sorted cloud):
 #define DNP_FAR 1
 #endif
 constexpr bool kPatchFar = DNP_FAR != 0;
+#ifndef DNP_TABLED_WAVES     // wavefronts per workgroup of the tabled scalar kernel (A/B builds: 1, 2, 4)
+#define DNP_TABLED_WAVES 2
+#endif
+constexpr int kTabledWaves = DNP_TABLED_WAVES;
 #ifndef DNP_FORCE_LDS   // A/B builds only (tools/gpu_ab_far.py): 1 sends the sorted layout through the LDS kernel too
 #define DNP_FORCE_LDS 0
 #endif
@@ -230,19 +234,21 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
             // patch-sorted cloud (what the drivers pass): contiguous sources -> the scalar-unit kernel
             const bool tabled = patch_box && tile_box && kPatchFar && pa.far_d2 > 0.f;
             const int ss = tabled ? source_split : 1;        // the source split exists for the fully tabled form only
-            const dim3 sgrid((unsigned)ceil_div(N, (int64_t)(kBlock / ss) * kPatchScalarKT), (unsigned)kn);
+            // the tabled, unsplit form runs in workgroups of kTabledWaves wavefronts (pair_kernel.h, WAVES)
+            const int waves = (tabled && ss == 1) ? kTabledWaves : kBlock / 64;
+            const dim3 sgrid((unsigned)ceil_div(N, (int64_t)(waves / ss) * 64 * kPatchScalarKT), (unsigned)kn);
             pa.chunk_box = patch_box;
             pa.tile_box = tile_box;
             pa.w_part = w_part ? w_part + k0 * ceil_div(N, (int64_t)64 * kPatchScalarKT) * 2 : nullptr;
-#define DNP_LAUNCH_TABLED(WP, SS)                                                                                        \
-    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, WP, SS>), \
-                       sgrid, dim3(kBlock), 0, st, pa)
+#define DNP_LAUNCH_TABLED(WP, SS, WV)                                                                                    \
+    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, WP, SS, WV>), \
+                       sgrid, dim3(WV * 64), 0, st, pa)
             if (tabled && w_part) {
-                if (ss == 4) DNP_LAUNCH_TABLED(true, 4);
-                else DNP_LAUNCH_TABLED(true, 1);
+                if (ss == 4) DNP_LAUNCH_TABLED(true, 4, 4);
+                else DNP_LAUNCH_TABLED(true, 1, kTabledWaves);
             } else if (tabled) {
-                if (ss == 4) DNP_LAUNCH_TABLED(false, 4);
-                else DNP_LAUNCH_TABLED(false, 1);
+                if (ss == 4) DNP_LAUNCH_TABLED(false, 4, 4);
+                else DNP_LAUNCH_TABLED(false, 1, kTabledWaves);
             }
 #undef DNP_LAUNCH_TABLED
             else if (patch_box && kPatchFar)

@@ -70,7 +70,10 @@ static inline hipError_t set_stamps_here(unsigned long long* p) {
 #define DNP_STAMP_END() do { } while (0)
 #endif
 
-constexpr int kBlock = 256;       // threads per workgroup (4 waves, one per SIMD)
+#ifndef DNP_BLOCK      // A/B builds only (64 / 128: finer dispatch granularity for the scalar kernel, whose wavefronts do not cooperate)
+#define DNP_BLOCK 256
+#endif
+constexpr int kBlock = DNP_BLOCK;       // threads per workgroup (4 waves, one per SIMD)
 #ifndef DNP_FLUSH
 #define DNP_FLUSH 32
 #endif
@@ -535,21 +538,26 @@ __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, cons
 // (the launchers do not pick SS > 1 for those).  A work item is up to SS times shorter, so the end of a launch - when
 // the last items run on a chip that is emptying - shrinks with it, for more workgroups with the same prologue; the
 // launchers use it for SHORT launches only (a rank's share of an 8-way sharded evaluation, small clouds).
+// WAVES: wavefronts per workgroup (launch with WAVES * 64 threads).  The wavefronts of this kernel do not cooperate
+// (SS = 1, boxes from tables), so the workgroup is only the unit of dispatch: 2 instead of 4 measured 1.4 % faster on
+// the bench launch (a CU takes a new pair of wavefronts as soon as two slots are free), 1 only 0.8 %
+// (profiles/r03_ab_block.txt).  SS > 1 needs WAVES = 4.
 template <typename F, typename PT, int MODE, int KT, int V, bool FAR = false, bool BOX = false, bool TBOX = false,
-          bool WPART = false, int SS = 1>
+          bool WPART = false, int SS = 1, int WAVES = kBlock / 64>
 #ifdef DNP_STAMP   // the stamps' extra stores tip hipcc's allocation from 61 to 78 VGPRs; the timeline build pins 8 waves per SIMD
-__global__ __launch_bounds__(kBlock, 8) void pair_kernel_scalar(const PairArgs<F, PT> a) {
+__global__ __launch_bounds__(WAVES * 64, 8) void pair_kernel_scalar(const PairArgs<F, PT> a) {
 #else
-__global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, PT> a) {
+__global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<F, PT> a) {
 #endif
     using M = Math<F>;
     constexpr int NC = (MODE == kField) ? 3 : 1;
     constexpr bool kFarPath = FAR && MODE == kField && V == kFast;
     static_assert(SS == 1 || SS == 2 || SS == 4, "source split: 1, 2 or 4 wavefronts per target tile");
     static_assert(SS == 1 || MODE == kField, "the source split is built for the field mode");
-    constexpr int kTG = (kBlock / 64) / SS;                 // target tiles per workgroup
+    static_assert(WAVES % SS == 0 && WAVES >= SS, "a workgroup holds whole target tiles");
+    constexpr int kTG = WAVES / SS;                         // target tiles per workgroup
     DNP_STAMP_BEGIN();
-    __shared__ F chunk_box[kBlock / 64][6];
+    __shared__ F chunk_box[WAVES][6];
     __shared__ double split_terms[SS > 1 ? SS - 1 : 1][SS > 1 ? kTG : 1][KT][SS > 1 ? NC : 1][SS > 1 ? 64 : 1];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // an SGPR: everything derived from it stays wave-uniform,
@@ -612,7 +620,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
             for (int c = 0; c < 3; ++c) { plo[c] = wave_min<F>(plo[c]); phi[c] = wave_max<F>(phi[c]); }
         } else if constexpr (!given) {
             F lo[3] = {M::kHuge, M::kHuge, M::kHuge}, hi[3] = {-M::kHuge, -M::kHuge, -M::kHuge};
-            for (int64_t q = s_begin + tid; q < s_end; q += kBlock) {
+            for (int64_t q = s_begin + tid; q < s_end; q += WAVES * 64) {
                 const F* p = src + (sidx ? sidx[q] : q) * ld;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { lo[c] = p[c] < lo[c] ? p[c] : lo[c]; hi[c] = p[c] > hi[c] ? p[c] : hi[c]; }
@@ -671,7 +679,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel_scalar(const PairArgs<F, P
             for (int c = 0; c < 3; ++c) {
                 F slo = chunk_box[0][c], shi = chunk_box[0][3 + c];
 #pragma unroll
-                for (int w = 1; w < kBlock / 64; ++w) {
+                for (int w = 1; w < WAVES; ++w) {
                     slo = chunk_box[w][c] < slo ? chunk_box[w][c] : slo;
                     shi = chunk_box[w][3 + c] > shi ? chunk_box[w][3 + c] : shi;
                 }

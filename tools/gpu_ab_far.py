@@ -83,10 +83,10 @@ def main():
         if name == "nobox":          # the product library without the box table: every workgroup finds its patch's box
             rc = libs[name].dnp_patch_fields_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch), 0, P,
                                                  1e-5, _lib.ptr(dE[name]), stream)
-        elif name in ("tiled", "tiledw"):
+        elif name in ("tiled", "tiledw") or name.startswith("tw"):     # AB_LIBS names tw*: a library through the tabled entry + partials
             rc = libs[name].dnp_patch_fields_tiled_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch),
                                                        _lib.ptr(boxes), _lib.ptr(tile_boxes), 0, P, 1e-5,
-                                                       _lib.ptr(dE[name]), _lib.ptr(w_part) if name == "tiledw" else None,
+                                                       _lib.ptr(dE[name]), _lib.ptr(w_part) if name != "tiled" else None,
                                                        1, stream)
         else:
             rc = libs[name].dnp_patch_fields_boxed_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch),
