@@ -571,7 +571,18 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
         s_begin = a.chunk_off[chunk];
         s_end = a.chunk_off[chunk + 1];
     }
-    const int64_t tile_base = (int64_t)blockIdx.x * (kTG * 64 * KT);
+    // XCD-aware tile mapping.  Workgroups are dealt round-robin over the 8 XCDs in launch order (x fastest: XCD = linear
+    // id mod 8 - observed behaviour, MI355X_MICROARCH.md; only speed depends on it).  With a grid width that is not a
+    // multiple of 8 a target tile would wander over the XCDs from one chunk row to the next, and every XCD's L2 would
+    // fetch every target row and take part in every output line: with 391-wide grids (two-wavefront workgroups) the
+    // kernel's L2 fetches were 148 MB per launch against 17 MB (profiles/r03_ab_block.txt).  So inside each aligned
+    // group of 8 x-blocks the tile index is rotated by the row's offset: tile t always runs on XCD t mod 8.
+#ifndef DNP_XCD_MAP
+#define DNP_XCD_MAP 1
+#endif
+    unsigned bx = blockIdx.x;
+    if (DNP_XCD_MAP && bx < (gridDim.x & ~7u)) bx = (bx & ~7u) | ((bx + blockIdx.y * gridDim.x) & 7u);
+    const int64_t tile_base = (int64_t)bx * (kTG * 64 * KT);
     F tx[KT], ty[KT], tz[KT];
     int64_t trow[KT];
 #pragma unroll
@@ -637,7 +648,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
             // entry for them either - round 3's first form read up to 72 bytes past its end, found by tools/gpu_fuzz.py
             // as a memory access fault when the table ended on a page boundary)
             const int64_t n_tiles = (a.T + 64 * KT - 1) / (64 * KT);
-            int64_t wave_tile = (int64_t)blockIdx.x * kTG + __builtin_amdgcn_readfirstlane(tg);
+            int64_t wave_tile = (int64_t)bx * kTG + __builtin_amdgcn_readfirstlane(tg);
             wave_tile = wave_tile < n_tiles ? wave_tile : n_tiles - 1;
             const F* tb = a.tile_box + wave_tile * 6;                       // wave-uniform: scalar loads
 #pragma unroll
@@ -837,7 +848,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
             w_other += __shfl_xor(w_other, off, 64);
         }
         const int64_t n_tiles = (a.T + 64 * KT - 1) / (64 * KT);
-        const int64_t wave_tile = (int64_t)blockIdx.x * kTG + tg;
+        const int64_t wave_tile = (int64_t)bx * kTG + tg;
         if ((tid & 63) == 0 && wave_tile < n_tiles) {
             double* wp = a.w_part + ((int64_t)chunk * n_tiles + wave_tile) * 2;
             wp[0] = w_first;
