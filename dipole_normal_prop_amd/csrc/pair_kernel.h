@@ -51,22 +51,46 @@
 
 namespace dnp {
 
-#ifdef DNP_STAMP   // timeline builds only (tools/gpu_timeline.py): every workgroup leaves its start / end time (100 MHz
-                   // wall clock) in a buffer set through dnp_debug_set_stamps; the product library has none of this
+#ifdef DNP_STAMP   // timeline builds only (tools/gpu_timeline.py); the product library has none of this.  Every
+                   // WAVEFRONT leaves four 64-bit words in a buffer set through dnp_debug_set_stamps_*: [0] its start time
+                   // (LDS kernel only), [1] its end time (100 MHz wall clock), [2] HW_ID | XCC_ID << 32 - the SIMD it ran on.
+                   // Everything goes through the scalar unit (s_memrealtime / s_getreg -> s_store, written back at once).
+                   // pair_kernel_scalar has NO start stamp: ANY instruction with a side effect in its prologue - vector
+                   // store, scalar store, a bare s_memrealtime kept in SGPRs - moves hipcc's allocation from 61 to 72-78
+                   // VGPRs (two wavefronts per SIMD less: that timeline was not the product's).  With end stamps alone the
+                   // allocation is the product's, and because a SIMD's slots are refilled at once while work is queued,
+                   // "wavefronts of SIMD x that end after t" IS its occupancy for every t after the last dispatch.
 static __device__ unsigned long long* g_stamps = nullptr;    // one per translation unit (no relocatable device code)
 static inline hipError_t set_stamps_here(unsigned long long* p) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p));
 }
-// (nothing stays live across the kernel: a start time kept in registers cost the scalar kernel 17 VGPRs and two waves)
-#define DNP_STAMP_AT(slot)                                                                                \
+__device__ inline unsigned long long* stamp_slot() {         // wave-uniform by construction; readfirstlane makes hipcc believe it
+    const unsigned long long q = (unsigned long long)(g_stamps + 4 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)));
+    return (unsigned long long*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(q >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)q));
+}
+#define DNP_STAMP_SLOT_() stamp_slot()
+#define DNP_STAMP_BEGIN()                                                                                 \
     do {                                                                                                  \
-        if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0)   /* a scalar branch: wave 0, every lane the same store */ \
-            g_stamps[2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + (slot)] = wall_clock64();        \
+        unsigned long long t_;                                                                            \
+        unsigned long long* q_ = DNP_STAMP_SLOT_();                                                       \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_));                               \
+        asm volatile("s_store_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::"s"(t_), "s"(q_)); \
     } while (0)
-#define DNP_STAMP_BEGIN() DNP_STAMP_AT(0)
-#define DNP_STAMP_END() DNP_STAMP_AT(1)
+#define DNP_STAMP_END()                                                                                   \
+    do {                                                                                                  \
+        unsigned long long t_;                                                                            \
+        unsigned h_, x_;                                                                                  \
+        unsigned long long* q_ = DNP_STAMP_SLOT_();                                                       \
+        asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\t" \
+                     "s_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(h_), "=s"(x_));                              \
+        asm volatile("s_store_dwordx2 %0, %3, 0x8\n\ts_store_dword %1, %3, 0x10\n\ts_store_dword %2, %3, 0x14\n\t" \
+                     "s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::"s"(t_), "s"(h_), "s"(x_), "s"(q_));        \
+    } while (0)
+#define DNP_STAMP_BEGIN_SCALAR() do { } while (0)
 #else
 #define DNP_STAMP_BEGIN() do { } while (0)
+#define DNP_STAMP_BEGIN_SCALAR() do { } while (0)
 #define DNP_STAMP_END() do { } while (0)
 #endif
 
@@ -544,11 +568,7 @@ __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, cons
 // (profiles/r03_ab_block.txt).  SS > 1 needs WAVES = 4.
 template <typename F, typename PT, int MODE, int KT, int V, bool FAR = false, bool BOX = false, bool TBOX = false,
           bool WPART = false, int SS = 1, int WAVES = kBlock / 64>
-#ifdef DNP_STAMP   // the stamps' extra stores tip hipcc's allocation from 61 to 78 VGPRs; the timeline build pins 8 waves per SIMD
-__global__ __launch_bounds__(WAVES * 64, 8) void pair_kernel_scalar(const PairArgs<F, PT> a) {
-#else
 __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<F, PT> a) {
-#endif
     using M = Math<F>;
     constexpr int NC = (MODE == kField) ? 3 : 1;
     constexpr bool kFarPath = FAR && MODE == kField && V == kFast;
@@ -556,7 +576,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
     static_assert(SS == 1 || MODE == kField, "the source split is built for the field mode");
     static_assert(WAVES % SS == 0 && WAVES >= SS, "a workgroup holds whole target tiles");
     constexpr int kTG = WAVES / SS;                         // target tiles per workgroup
-    DNP_STAMP_BEGIN();
+    DNP_STAMP_BEGIN_SCALAR();
     __shared__ F chunk_box[WAVES][6];
     __shared__ double split_terms[SS > 1 ? SS - 1 : 1][SS > 1 ? kTG : 1][KT][SS > 1 ? NC : 1][SS > 1 ? 64 : 1];
     const int tid = threadIdx.x;

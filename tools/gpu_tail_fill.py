@@ -18,6 +18,7 @@ from tools.workloads import headline_workload  # noqa: E402
 
 dev = torch.device("cuda:0")
 lib = _lib.require_device()
+BEHIND = os.path.join(ROOT, "tools", "bin", "libdnp_tailbehind.so")      # -DDNP_TAIL_BEHIND=1: source_split = -k
 pc, patches, _ = headline_workload()
 off, idx, sizes = util.patch_csr(patches, dev)
 pts = pc.to(dev)[idx].contiguous()
@@ -73,3 +74,28 @@ for K in (32, 256):
                     e2.record(hi_s)
                     main.wait_event(e2)
             print(f"   last {k} patches split x4 on a second stream ({label}): {timed(both)}")
+
+# Second form (same round): ONE stream, the tail launch dispatched BEHIND the main launch without a barrier
+# (dnp_patch_fields_tiled_f32 source_split = -k -> hipExtAnyOrderLaunch): the command processor starts the tail's
+# workgroups when the main launch has none left to start.
+print("# tail launch behind the main launch on the same stream, no barrier (source_split = -k); interleaved with the single launch")
+if not os.path.exists(BEHIND):
+    from dipole_normal_prop_amd import build
+    build.build(extra_flags=["-DDNP_TAIL_BEHIND=1"], out=BEHIND, verbose=False)
+lib = ctypes.CDLL(BEHIND)
+lib.dnp_patch_fields_tiled_f32.restype, lib.dnp_patch_fields_tiled_f32.argtypes = _lib.SIGNATURES["dnp_patch_fields_tiled_f32"]
+for K in (16, 32, 64, 256):
+    launch(0, K, 1, main)
+    torch.cuda.synchronize()
+    ref, wref = dE[:K].clone(), wp[:K].clone()
+    line = f"K={K}: single {timed(lambda: launch(0, K, 1, main))}"
+    for k in (1, 2, 3, 4, 6, 8, 12):
+        if k >= K:
+            continue
+        dE[:K].zero_()
+        launch(0, K, -k, main)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(dE[:K], ref)) and bool(torch.equal(wp[:K], wref))
+        line += f"   -{k}: {timed(lambda: launch(0, K, -k, main), reps=30)}{'' if same else ' RESULTS DIFFER'}"
+    line += f"   single again {timed(lambda: launch(0, K, 1, main))}"
+    print(line, flush=True)
