@@ -3,7 +3,9 @@
 // (field_utils.strongest_field_propagation{,_reps}, field_utils.py:207-348).
 #include <math.h>
 
+#ifdef DNP_TAIL_BEHIND
 #include <hip/hip_ext.h>
+#endif
 
 #include "dnp_common.h"
 #include "pair_kernel.h"
@@ -274,9 +276,15 @@ static int patch_fields_tiled(const float* pts, int64_t N, int64_t ld_pts, const
             pa.chunk_box = patch_box;
             pa.tile_box = tile_box;
             pa.w_part = w_part ? w_part + k0 * ceil_div(N, (int64_t)64 * kPatchScalarKT) * 2 : nullptr;
+#ifdef DNP_TAIL_BEHIND
 #define DNP_LAUNCH_TABLED(WP, SS, WV)                                                                                    \
     hipExtLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, WP, SS, WV>), \
                           sgrid, dim3(WV * 64), 0, st, nullptr, nullptr, behind ? hipExtAnyOrderLaunch : 0, pa)
+#else
+#define DNP_LAUNCH_TABLED(WP, SS, WV)                                                                                    \
+    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, WP, SS, WV>), \
+                       sgrid, dim3(WV * 64), 0, st, pa)
+#endif
             if (tabled && w_part) {
                 if (ss == 4) DNP_LAUNCH_TABLED(true, 4, 4);
                 else DNP_LAUNCH_TABLED(true, 1, kTabledWaves);
