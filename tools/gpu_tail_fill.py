@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Experiment: fill the tail of a patch-mode launch with short items.  The last k of K patches are evaluated by a second
+"""Experiment: fill the tail of a patch-mode launch with short items (two forms: second stream; same stream without a barrier).  The last k of K patches are evaluated by a second
 launch with source_split = 4 (items a third as long; results bit-identical) on a LOW-priority stream while the first K - k
 run on the normal stream: if the hardware honours the priorities the short items flow in when the long ones run out.
 Total time (fork -> join) against the single launch, K = 32 and 256, several k."""
