@@ -563,9 +563,9 @@ __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, cons
 // the last items run on a chip that is emptying - shrinks with it, for more workgroups with the same prologue; the
 // launchers use it for SHORT launches only (a rank's share of an 8-way sharded evaluation, small clouds).
 // WAVES: wavefronts per workgroup (launch with WAVES * 64 threads).  The wavefronts of this kernel do not cooperate
-// (SS = 1, boxes from tables), so the workgroup is only the unit of dispatch: 2 instead of 4 measured 1.4 % faster on
-// the bench launch (a CU takes a new pair of wavefronts as soon as two slots are free), 1 only 0.8 %
-// (profiles/r03_ab_block.txt).  SS > 1 needs WAVES = 4.
+// (SS = 1, boxes from tables), so the workgroup is only the unit of dispatch: with the XCD-aware tile mapping below, 2
+// wavefronts measured 4.049 ms on the bench launch against 4.074 with 4 (a CU takes a new pair of wavefronts as soon as
+// two slots are free) and 4.060 with 1 (profiles/r03_ab_block.txt).  SS > 1 needs WAVES = 4.
 template <typename F, typename PT, int MODE, int KT, int V, bool FAR = false, bool BOX = false, bool TBOX = false,
           bool WPART = false, int SS = 1, int WAVES = kBlock / 64>
 __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<F, PT> a) {
