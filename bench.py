@@ -139,6 +139,17 @@ def other_configs(dev, fu, util, pts_sorted, patch_ranges):
     t = timed(lambda: fu.reference_field(pts_sorted, tgt), 5)
     out["config5_reference_field_100k_to_100k"] = {"sources": N_POINTS, "targets": N_POINTS, "ms": t * 1e3,
                                                    "pairs_per_s": float(N_POINTS) ** 2 / t, "dtype": "f32"}
+    # the same two calls with HOST tensors in and out (the reference's functions take either): H2D + D2H of the cloud
+    # over PCIe inside the timed call.  Never the headline value (inputs resident in HBM there) - DESIGN.md section 5.
+    host = pts_sorted.cpu()       # oriented in place call after call (a torch CPU clone of 2.4 MB inside the timed loop costs
+    #                               3-50 ms where the process sees more cores than its CPU quota - not the path's time)
+    t = timed(lambda: fu.strongest_field_propagation(host, list(enumerate(patch_ranges)), patch_ranges,
+                                                     diffuse=True), 5)
+    out["config4_patch_driver_host_tensors"] = {"points": N_POINTS, "patches": N_PATCHES, "ms": t * 1e3,
+                                                "pairs_per_s_pcie_inclusive": float(N_POINTS) ** 2 / t}
+    t = timed(lambda: fu.field_grad(host, host), 5)
+    out["allpairs_100k_field_grad_host_tensors"] = {"points": N_POINTS, "ms": t * 1e3,
+                                                    "pairs_per_s_pcie_inclusive": float(N_POINTS) ** 2 / t}
     return out
 
 

@@ -378,6 +378,16 @@ def reference_field(pc1, pc2):
         fused = _reference_field_fused(pc1, pc2)
         if fused is not None:
             return fused
+        if not pc1.is_cuda and not pc2.is_cuda and pc1.dtype == pc2.dtype and pc2.dim() == 2 and pc2.shape[1] in (3, 6):
+            # two HOST tensors: stage both, the same single library call, results back (the 6-column form in place)
+            dev = _compute_device()
+            staged = pc2.detach().to(dev).contiguous()
+            fused = _reference_field_fused(pc1.detach().to(dev), staged)
+            if fused is not None:
+                if pc2.shape[1] == 3:
+                    return fused.to(pc2.device)
+                _store_normals(pc2, staged[:, 3:])
+                return pc2
         E = field_grad(pc1, pc2, recursive=True)
         if pc2.shape[1] == 3:
             length = E.norm(dim=-1)
@@ -770,7 +780,7 @@ def _finish_batched(pts: torch.Tensor, st: "_Batched", diffuse: bool, listed_pat
                                       int(out.dtype == torch.float64), _lib.current_stream())
     _lib.check(rc)
     if not direct:
-        pts[:, 3:] = out[:, 3:].to(device=pts.device, dtype=pts.dtype)
+        _store_normals(pts, out[:, 3:])
 
 
 def _listed_patches(patches, all_patches, dev) -> Optional[torch.Tensor]:
@@ -961,6 +971,17 @@ def _sequential_patch_propagation(work, patches: List[torch.Tensor], start: int,
     return np.array(order), sigma, np.array(chosen), E
 
 
+def _store_normals(pts: torch.Tensor, normals: torch.Tensor) -> None:
+    """pts[:, 3:] = normals for the caller's tensor on any device / float dtype.  For a HOST tensor the rows go over
+    PCIe as one contiguous copy and into the strided column view through numpy: torch's CPU copy kernel splits these
+    300 000 elements over every core it sees, and in a container with a CPU quota (16 of a box's 192+) that is 22 ms of
+    oversubscribed threads for a 1.2 MB copy (tools/gpu_host_boundary.py) - 5x the whole propagation."""
+    if pts.is_cuda or pts.dtype not in (torch.float32, torch.float64) or pts.requires_grad:
+        pts[:, 3:] = normals.to(device=pts.device, dtype=pts.dtype)
+        return
+    pts.numpy()[:, 3:] = normals.contiguous().cpu().numpy()
+
+
 def _prepare_work(pts: torch.Tensor, weights):
     """Device fp32 working copy of pts (normals scaled by clamp(weights, 0.1, 1))."""
     dev = pts.device if pts.is_cuda else _compute_device()
@@ -977,7 +998,7 @@ def _prepare_work(pts: torch.Tensor, weights):
 def _finish_patch_driver(pts, work, w):
     if w is not None:
         work[:, 3:] = work[:, 3:] / w[:, None]
-    pts[:, 3:] = work[:, 3:].to(device=pts.device, dtype=pts.dtype)
+    _store_normals(pts, work[:, 3:])
 
 
 def strongest_field_propagation(pts, patches, all_patches, diffuse=False, weights=None, start_patch=None):
@@ -1142,7 +1163,7 @@ def strongest_field_propagation_points(pts: torch.Tensor, diffuse=False, startin
                 done = False
         if not done:
             order = _points_stepwise(work, diffuse, int(starting_point))
-        pts[:, 3:] = work[:, 3:].to(device=pts.device, dtype=pts.dtype)
+        _store_normals(pts, work[:, 3:])
         _set_trace("points", order=order)
         return pts
 

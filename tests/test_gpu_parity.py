@@ -164,8 +164,20 @@ def test_reference_field_fused_call_equals_the_two_step_form(dev, monkeypatch):
         got = fu.reference_field(a, view[:, :3])                      # 3-column view, row stride 6
         assert torch.equal(got, one)
     assert np.array_equal(fu.reference_field(src, tgt6.clone()).cpu().numpy(), g["out6"])
-    # CPU tensors: staged two-step form, same decisions
-    assert np.array_equal(fu.reference_field(src.cpu(), tgt6.cpu().clone()).numpy(), g["out6"])
+    # CPU tensors: staged, the same library call, results back (6 columns in place, also into a strided view, fp64 too)
+    host6 = tgt6.cpu().clone()
+    back = fu.reference_field(src.cpu(), host6)
+    assert back.data_ptr() == host6.data_ptr() and np.array_equal(host6.numpy(), g["out6"])
+    wide = torch.zeros(10000, 8)
+    wide[:, 1:7] = tgt6.cpu()
+    fu.reference_field(src.cpu(), wide[:, 1:7])
+    assert np.array_equal(wide[:, 1:7].numpy(), g["out6"]) and float(wide[:, 0].abs().max()) == 0 and float(wide[:, 7].abs().max()) == 0
+    h3 = fu.reference_field(src.cpu(), tgt3.cpu())
+    assert h3.device.type == "cpu" and torch.equal(h3, fu.reference_field(src, tgt3).cpu())
+    h64, d64 = tgt6.cpu().double().clone(), tgt6.double().clone()
+    fu.reference_field(src.cpu().double(), h64)
+    fu.reference_field(src.double(), d64)
+    assert torch.equal(h64, d64.cpu())
     # empty sets
     e = fu.reference_field(src[:0], tgt3[:5].clone())
     assert e.shape == (5, 6) and float(e[:, 3:].abs().max()) == 0
@@ -670,6 +682,16 @@ def test_G6_cpu_tensor_input_default_start(dev, tag):
     assert np.array_equal(tr["order"], g[f"order_{tag}"])
     assert pts.device.type == "cpu"
     assert np.array_equal(((pts[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g[f"sign_{tag}"])
+    # the same normals as a device run, bit for bit; xyz untouched; an fp64 host tensor and a strided host view likewise
+    ref = cloud.clone().to(dev)
+    allp_d = [p.to(dev) for p in allp]
+    fu.strongest_field_propagation(ref, [(i, allp_d[i]) for i, _ in patches], allp_d, diffuse=diffuse,
+                                   weights=None if w is None else w.to(dev))
+    assert torch.equal(pts, ref.cpu())
+    wide = torch.zeros(cloud.shape[0], 8, dtype=torch.float64)
+    wide[:, 1:7] = cloud.double()
+    fu.strongest_field_propagation(wide[:, 1:7], patches, allp, diffuse=diffuse, weights=w)
+    assert torch.equal(wide[:, 1:7], ref.cpu().double()) and float(wide[:, 0].abs().max()) == 0 and float(wide[:, 7].abs().max()) == 0
 
 
 def test_start_patch_rule_matches_the_reference_curvatures(dev):
