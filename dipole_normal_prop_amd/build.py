@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdnp.so")
 SOURCES = ["dnp_api.hip", "dnp_field.hip", "dnp_patch.hip", "dnp_greedy.hip", "dnp_xie.hip", "dnp_prep.hip", "dnp_io.hip"]
 HEADERS = ["dnp_common.h", "pair_kernel.h", os.path.join("..", "..", "include", "dnp.h")]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-unused-function",
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-pthread", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-fno-slp-vectorize"]
 
 

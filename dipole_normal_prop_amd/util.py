@@ -60,9 +60,9 @@ def _format_rows_native(rows: torch.Tensor):
         return None
     arr = np.ascontiguousarray(rows.numpy())
     cap = int(lib.dnp_xyz_format_bound(arr.shape[0], arr.shape[1]))
-    buf = ctypes.create_string_buffer(cap)
-    n = lib.dnp_xyz_format_f32(arr.ctypes.data, arr.shape[0], arr.shape[1], buf, cap)
-    return buf.raw[:n] if n >= 0 else None
+    buf = np.empty(cap, dtype=np.uint8)        # not create_string_buffer: that zero-fills 15 MB and .raw copies them again
+    n = lib.dnp_xyz_format_f32(arr.ctypes.data, arr.shape[0], arr.shape[1], buf.ctypes.data, cap)
+    return memoryview(buf)[:n] if n >= 0 else None       # written to the file as it is (bytes-like)
 
 
 def _xyz_native(txt: str, append_normals: bool):
@@ -74,8 +74,8 @@ def _xyz_native(txt: str, append_normals: bool):
     except Exception:
         return None
     raw = txt.encode()
-    max_rows = raw.count(b"\n") + 1
-    out = np.empty((max_rows, 6), dtype=np.float32)
+    max_rows = len(raw) // 6 + 1               # a row is at least "1 2 3\n" (counting the newlines costs 4 ms per 7 MB; the
+    out = np.empty((max_rows, 6), dtype=np.float32)   # pages of the over-sized buffer that are never written are never touched)
     ncol = ctypes.c_int32(0)
     n = lib.dnp_xyz_parse_f32(raw, len(raw), out.ctypes.data, max_rows, ctypes.byref(ncol))
     if n <= 0 or ncol.value not in (3, 6):
@@ -83,7 +83,7 @@ def _xyz_native(txt: str, append_normals: bool):
     arr = out.reshape(-1)[: n * ncol.value].reshape(n, ncol.value)
     if ncol.value == 3 and append_normals:
         arr = np.concatenate([arr, np.zeros((n, 3), dtype=np.float32)], axis=1)
-    return torch.from_numpy(np.ascontiguousarray(arr))
+    return torch.from_numpy(np.array(arr))      # a copy of the rows: the over-sized buffer goes
 
 
 def _xyz_fast(txt: str, append_normals: bool):

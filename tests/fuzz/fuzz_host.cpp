@@ -75,7 +75,43 @@ static int fuzz_text(std::mt19937_64& rng, int iterations) {
     free(o);
     printf("text: %ld accepted, %ld rejected / empty; %lld of %lld bytes for random bit patterns\n", parsed, rejected,
            (long long)w, (long long)cap);
-    return (w > 0 && w <= cap) ? 0 : 1;
+    if (!(w > 0 && w <= cap)) return 1;
+    // texts long enough for the threaded paths (blocks of lines on several host threads): format -> parse round trip with
+    // blank lines and CRLF sprinkled in, a row-capacity error, and an irregular line deep inside a late block
+    for (int round = 0; round < 6; ++round) {
+        const int cols = (round & 1) ? 3 : 6;
+        const int64_t rows = 20000 + (int64_t)(rng() % 30000);
+        std::vector<float> v((size_t)(rows * cols));
+        for (auto& x : v) x = (float)((double)(int64_t)(rng() % 2000000) / 1e3 - 1e3) * ((rng() & 7) ? 1.f : 1e-9f);
+        const int64_t c2 = dnp_xyz_format_bound(rows, cols);
+        std::vector<char> txt((size_t)c2);
+        const int64_t w2 = dnp_xyz_format_f32(v.data(), rows, cols, txt.data(), c2);
+        if (w2 <= 0 || w2 > c2) { printf("long format wrote %lld of %lld\n", (long long)w2, (long long)c2); return 1; }
+        std::string loose;
+        for (int64_t i = 0; i < w2; ++i) {
+            if (txt[(size_t)i] == '\n' && (rng() % 50) == 0) loose += (rng() & 1) ? "\r\n\n" : "\n \n";
+            else loose += txt[(size_t)i];
+        }
+        const std::string* forms[2] = {nullptr, &loose};
+        for (const std::string* t : forms) {
+            const char* p = t ? t->data() : txt.data();
+            const int64_t len = t ? (int64_t)t->size() : w2;
+            std::vector<float> back((size_t)(rows * cols));
+            int32_t nc = 0;
+            const int64_t n = dnp_xyz_parse_f32(p, len, back.data(), rows, &nc);
+            if (n != rows || nc != cols || memcmp(back.data(), v.data(), sizeof(float) * v.size()) != 0) {
+                printf("long round trip: %lld rows of %lld, %d columns\n", (long long)n, (long long)rows, nc);
+                return 1;
+            }
+            if (dnp_xyz_parse_f32(p, len, back.data(), rows - 1, &nc) != DNP_EWORKSPACE) { printf("row capacity not enforced\n"); return 1; }
+        }
+        std::string bad(txt.data(), (size_t)w2);
+        bad[bad.size() - 1 - (size_t)(rng() % 2000)] = 'x';
+        int32_t nc = 0;
+        std::vector<float> back((size_t)(rows * cols));
+        if (dnp_xyz_parse_f32(bad.data(), (int64_t)bad.size(), back.data(), rows, &nc) != -2) { printf("irregular tail accepted\n"); return 1; }
+    }
+    return 0;
 }
 
 // brute-force statement of the merge rule: live cells own voxel lists; adjacency by scanning every voxel pair
