@@ -340,7 +340,11 @@ int dnp_xie_order_f32(const float* M, int64_t N, const int64_t* order, int64_t R
  * dnp_xyz_parse_f32: text whose non-blank lines all hold the same number (3 or 6) of single-space separated
  * numbers -> out[rows, *ncol] (each token parsed as a double and rounded to float, as float(c) + torch.tensor(...,
  * float32) do).  Returns the row count, or -2 when the text is not of that regular form (a "nan" token, double
- * spaces, ragged lines, ...: the caller then takes the line-by-line path that defines the semantics).
+ * spaces, ragged lines, ...: the caller then takes the line-by-line path that defines the semantics);
+ * DNP_EWORKSPACE when the text holds more than max_rows rows.
+ *
+ * Both work on up to 8 host threads for long inputs (blocks of rows / of whole lines, results laid end to end: the
+ * bytes, the rows and the verdict of a single pass); they are reentrant and touch no device state.
  */
 int64_t dnp_xyz_format_bound(int64_t n_rows, int64_t n_cols);
 int64_t dnp_xyz_format_f32(const float* rows, int64_t n_rows, int64_t n_cols, char* out, int64_t cap);
