@@ -4,12 +4,12 @@
 //
 // xie_pairs: the per-pair "reflected normal"  ref[t][s] = (n_s - C (n_s.r^) r^) / |r|^3,  r = x_s - x_t,
 // not divided when |r| == 0 (so a coincident pair yields n_s itself), and its projection on the target
-// normal M[t][s] = ref[t][s] . n_t with NaN/Inf -> 0.  The OUTPUT is the whole T x S matrix, so the kernel is
-// bound by HBM writes (4 or 12 bytes per pair against ~40 flops): lanes run along the source index so that
-// every store instruction writes 256 contiguous bytes of a row, targets are staged through LDS and broadcast.
-// Being write-bound, the arithmetic mirrors the reference's IEEE op order (sqrt, divisions, no fma
-// contraction) instead of the rsq/rcp chain of pair_kernel.h: the ordered propagation takes sign decisions on
-// row sums of this matrix.
+// normal M[t][s] = ref[t][s] . n_t with NaN/Inf -> 0.  The OUTPUT is the whole T x S matrix (4 or 12 bytes per pair):
+// lanes run along the source index so that every store instruction writes 256 contiguous bytes of a row, targets are
+// staged through LDS and broadcast.  The arithmetic is the reference's IEEE op order bit for bit (sqrt, divisions, no fma
+// contraction) instead of the rsq/rcp chain of pair_kernel.h: the ordered propagation takes sign decisions on row sums of
+// this matrix.  Measured (profiles/r03_xie_time.txt): the tensor form is bound by its HBM writes (4.5-5.6 TB/s), the
+// matrix form by that arithmetic (2 TB/s written, 510 Gpairs/s) - see Recip and ieee_sqrt below for what it costs.
 //
 // xie_order: for each of R visiting orders, N sequential steps  inter[idx] = sum_j M[idx][j] * w[j];
 // w[idx] = inter[idx] < 0 ? -1 : +1  (w starts at 0, so only visited points contribute).  One persistent
@@ -32,9 +32,46 @@ struct XieArgs {
     F* out;
 };
 
+// correctly rounded square root in the operand's own precision (__builtin_sqrt on a float is the DOUBLE root: v_rsq_f64 and
+// eight fp64 fmas per pair until round 3 - the same bits, since a double root rounded to float is the correctly rounded
+// float root, at several times the cost)
+__device__ inline float ieee_sqrt(float x) { return __builtin_sqrtf(x); }
+__device__ inline double ieee_sqrt(double x) { return __builtin_sqrt(x); }
+
+// IEEE division by a SHARED denominator.  hipcc expands a / b in fp32 to div_scale, rcp, one Newton step on the reciprocal,
+// q0 = a r, two residual corrections (the last one in div_fmas) and div_fixup - 11 instructions and a transcendental per
+// quotient, and the pair body divides three numbers by |R| and three by |R|^3.  Outside the exponent extremes (where
+// div_scale rescales and div_fixup patches) that expansion IS  r = rcp(b); r += r (1 - b r);  q = a r;  q += r (a - b q)
+// twice - so the refined reciprocal is computed once per denominator and every quotient costs five instructions, with the
+// same bits as the compiler's division for operands in the normal range (checked against a -DDNP_XIE_IEEE_DIV=1 build on
+// 10^8 pairs, tools/gpu_xie_time.py).  fp64 keeps the compiler's division (its expansion differs; that form is not timed).
+#ifndef DNP_XIE_IEEE_DIV
+#define DNP_XIE_IEEE_DIV 0
+#endif
 template <typename F>
+struct Recip {
+    F b, r;
+    __device__ explicit Recip(F den) : b(den), r(F(0)) {
+        if constexpr (sizeof(F) == 4 && !DNP_XIE_IEEE_DIV) {
+            const float r0 = __builtin_amdgcn_rcpf(den);
+            r = __builtin_fmaf(__builtin_fmaf(-den, r0, 1.0f), r0, r0);
+        }
+    }
+    __device__ F divide(F a) const {
+        if constexpr (sizeof(F) == 4 && !DNP_XIE_IEEE_DIV) {
+            float q = a * r;
+            q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+            q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+            return q;
+        } else {
+            return a / b;
+        }
+    }
+};
+
+template <typename F, bool VEC>
 __global__ __launch_bounds__(kXieBlock) void xie_pairs_kernel(const XieArgs<F> a) {
-    __shared__ F tl[kXieTargets][6];
+    __shared__ __attribute__((aligned(16))) F tl[kXieTargets][8];       // rows of 8: one wide LDS read per half row
     const int tid = threadIdx.x;
     const int64_t s = (int64_t)blockIdx.x * kXieBlock + tid;
     const int64_t t0 = (int64_t)blockIdx.y * kXieTargets;
@@ -47,25 +84,28 @@ __global__ __launch_bounds__(kXieBlock) void xie_pairs_kernel(const XieArgs<F> a
     if (s >= a.S) return;
     const F* ps = a.src + s * a.ld_src;
     const F sx = ps[0], sy = ps[1], sz = ps[2], nx = ps[3], ny = ps[4], nz = ps[5];
-    for (int r = 0; r < nt; ++r) {
+    F* po = a.out + (t0 * a.S + s) * (VEC ? 3 : 1);                  // one 64-bit address, then a constant stride per target
+    const int64_t step = a.S * (VEC ? 3 : 1);
+    for (int r = 0; r < nt; ++r, po += step) {
         const F rx = sx - tl[r][0], ry = sy - tl[r][1], rz = sz - tl[r][2];      // R = source - target
-        const F nrm = __builtin_sqrt(rx * rx + ry * ry + rz * rz);
-        F fx, fy, fz;
-        if (nrm == F(0)) {
-            fx = nx; fy = ny; fz = nz;                    // R_unit = 0: n_s - C*0 ; not divided by |R|^3
-        } else {
-            const F ux = rx / nrm, uy = ry / nrm, uz = rz / nrm;
-            const F d = a.C * (nx * ux + ny * uy + nz * uz);
-            const F n3 = nrm * nrm * nrm;
-            fx = (nx - d * ux) / n3; fy = (ny - d * uy) / n3; fz = (nz - d * uz) / n3;
-        }
-        const int64_t o = (t0 + r) * a.S + s;
-        if (a.vector_out) {
-            a.out[o * 3 + 0] = fx; a.out[o * 3 + 1] = fy; a.out[o * 3 + 2] = fz;
+        const F nrm = ieee_sqrt(rx * rx + ry * ry + rz * rz);
+        // the quotients of the general case, computed for every lane (IEEE divisions: the reference's op order); a lane
+        // with |R| == 0 - the diagonal of a self matrix - takes n_s instead: R_unit = 0 there and nothing is divided
+        const Recip<F> by_nrm(nrm);
+        const F ux = by_nrm.divide(rx), uy = by_nrm.divide(ry), uz = by_nrm.divide(rz);
+        const F d = a.C * (nx * ux + ny * uy + nz * uz);
+        const F n3 = nrm * nrm * nrm;
+        const Recip<F> by_n3(n3);
+        const bool coincident = nrm == F(0);
+        const F fx = coincident ? nx : by_n3.divide(nx - d * ux);
+        const F fy = coincident ? ny : by_n3.divide(ny - d * uy);
+        const F fz = coincident ? nz : by_n3.divide(nz - d * uz);
+        if constexpr (VEC) {
+            po[0] = fx; po[1] = fy; po[2] = fz;
         } else {
             F v = fx * tl[r][3] + fy * tl[r][4] + fz * tl[r][5];
             if (!__builtin_isfinite(v)) v = F(0);           // intersaction[isnan / isinf] = 0
-            a.out[o] = v;
+            po[0] = v;
         }
     }
 }
@@ -113,8 +153,9 @@ static int run_xie_pairs(const F* src, int64_t S, int64_t ld_src, const F* tgt, 
     const int64_t gy = ceil_div(T, (int64_t)kXieTargets);
     DNP_REQUIRE(gy <= 65535, "T=%lld exceeds %d targets per launch", (long long)T, 65535 * kXieTargets);
     XieArgs<F> a{src, S, ld_src, tgt, T, ld_tgt, C, vector_out, out};
-    hipLaunchKernelGGL((xie_pairs_kernel<F>), dim3((unsigned)ceil_div(S, (int64_t)kXieBlock), (unsigned)gy),
-                       dim3(kXieBlock), 0, stream, a);
+    const dim3 grid((unsigned)ceil_div(S, (int64_t)kXieBlock), (unsigned)gy);
+    if (vector_out) hipLaunchKernelGGL((xie_pairs_kernel<F, true>), grid, dim3(kXieBlock), 0, stream, a);
+    else hipLaunchKernelGGL((xie_pairs_kernel<F, false>), grid, dim3(kXieBlock), 0, stream, a);
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
 }

@@ -135,3 +135,39 @@ def test_xie_pairs_ragged_against_oracle(dev):
     ref = O.xie_intersaction(src.double(), tgt.double(), C=2.5).numpy()
     m = fu.xie_intersaction(src.to(dev), tgt.to(dev), eps=0.0, knn_mask=-1, C=2.5).cpu().numpy()
     assert np.abs(m - ref).max() / np.abs(ref).max() < 1e-5
+
+
+def _torch_op_by_op(src, tgt, C):
+    """The pair body as separate torch kernels on the device - every operation IEEE-rounded on its own, in the kernel's
+    (= the reference's, field_utils.py xie_field) order; no contraction can happen across torch kernels."""
+    r = src[None, :, :3] - tgt[:, None, :3]
+    rx, ry, rz = r[..., 0], r[..., 1], r[..., 2]
+    nrm = torch.sqrt((rx * rx + ry * ry) + rz * rz)
+    ux, uy, uz = rx / nrm, ry / nrm, rz / nrm
+    nx, ny, nz = src[None, :, 3], src[None, :, 4], src[None, :, 5]
+    d = C * ((nx * ux + ny * uy) + nz * uz)
+    n3 = (nrm * nrm) * nrm
+    zero = nrm == 0
+    f = [torch.where(zero, n.expand_as(nrm), (n - d * u) / n3) for n, u in ((nx, ux), (ny, uy), (nz, uz))]
+    m = (f[0] * tgt[:, None, 3] + f[1] * tgt[:, None, 4]) + f[2] * tgt[:, None, 5]
+    return torch.stack(f, -1), torch.where(torch.isfinite(m), m, torch.zeros_like(m))
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-3, 37.0])
+def test_xie_pairs_are_the_ieee_op_order_bit_for_bit(dev, scale):
+    """The kernel divides by shared, refined reciprocals and takes the fp32 root directly (round 3, csrc/dnp_xie.hip) -
+    claimed to be the bits of IEEE division / sqrt applied operation by operation.  Checked against exactly that: the
+    same expression as separate torch kernels, on random clouds at three length scales, with coincident pairs."""
+    gen = torch.Generator().manual_seed(int(scale * 1000) + 3)
+    src = torch.randn(1300, 6, generator=gen)
+    tgt = torch.randn(900, 6, generator=gen)
+    src[:, :3] *= scale
+    tgt[:, :3] *= scale
+    tgt[:50, :3] = src[100:150, :3]                                   # coincident pairs: |R| == 0
+    src, tgt = src.to(dev), tgt.to(dev)
+    for C in (3.0, 2.5):
+        want_f, want_m = _torch_op_by_op(src, tgt, C)
+        got_f = fu.xie_field(src, tgt, eps=0.1, C=C)
+        got_m = fu.xie_intersaction(src, tgt, eps=0.1, knn_mask=-1, C=C)
+        assert torch.equal(got_f, want_f), float((got_f - want_f).abs().max())
+        assert torch.equal(got_m, want_m), float((got_m - want_m).abs().max())

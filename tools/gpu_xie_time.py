@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""The xie pair kernels against their roofline (HBM writes): xie_intersaction (T x S matrix, 4 B per pair) and xie_field
+(T x S x 3, 12 B per pair) at N = 4 000 / 10 000 / 16 000 points, through the C ABI (dnp_xie_pairs_f32) with the output
+buffer reused, and through the host mirror (which allocates the result); the ordered propagation per step.
+    python tools/gpu_xie_time.py   (on the GPU box)"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dipole_normal_prop_amd import _lib  # noqa: E402
+from dipole_normal_prop_amd import field_utils as fu  # noqa: E402
+
+dev = torch.device("cuda:0")
+lib = _lib.require_device()
+IEEE = os.path.join(ROOT, "tools", "bin", "libdnp_xie_ieee.so")      # -DDNP_XIE_IEEE_DIV=1: the compiler's own division per quotient
+if not os.path.exists(IEEE):
+    from dipole_normal_prop_amd import build
+    build.build(extra_flags=["-DDNP_XIE_IEEE_DIV=1"], out=IEEE, verbose=False)
+ieee = ctypes.CDLL(IEEE)
+ieee.dnp_xie_pairs_f32.restype, ieee.dnp_xie_pairs_f32.argtypes = _lib.SIGNATURES["dnp_xie_pairs_f32"]
+
+
+def timed(fn, reps=20):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return float(np.median(ts)), float(np.min(ts))
+
+
+g = torch.Generator().manual_seed(5)
+for n in (4000, 10000, 16000):
+    x = torch.randn(n, 3, generator=g)
+    pc = torch.cat([x / x.norm(dim=1, keepdim=True), torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)], 1).to(dev)
+    stream = _lib.current_stream()
+    for vec, label in ((0, "matrix"), (1, "field ")):
+        out = torch.empty((n, n, 3) if vec else (n, n), dtype=torch.float32, device=dev)
+        med, mn = timed(lambda: lib.dnp_xie_pairs_f32(_lib.ptr(pc), n, 6, _lib.ptr(pc), n, 6, 3.0, vec, _lib.ptr(out), stream))
+        gb = out.numel() * 4 / 1e9
+        ref = torch.empty_like(out)
+        assert ieee.dnp_xie_pairs_f32(_lib.ptr(pc), n, 6, _lib.ptr(pc), n, 6, 3.0, vec, _lib.ptr(ref), stream) == 0
+        med_i, mn_i = timed(lambda: ieee.dnp_xie_pairs_f32(_lib.ptr(pc), n, 6, _lib.ptr(pc), n, 6, 3.0, vec, _lib.ptr(ref), stream))
+        same = bool(torch.equal(out, ref))
+        print(f"N={n:6d} xie {label} with the compiler's division per quotient: {mn_i * 1e3:8.1f} us min; results bit-identical: {same}")
+        print(f"N={n:6d} xie {label} C ABI: {med * 1e3:8.1f} us median / {mn * 1e3:8.1f} min   {gb / mn * 1e3:7.1f} GB/s written "
+              f"({gb * 1e3:.0f} MB), {n * n / mn / 1e6:.1f} Gpairs/s")
+    med, mn = timed(lambda: fu.xie_intersaction(pc, pc, 0.1, -1, 3), reps=10)
+    print(f"N={n:6d} fu.xie_intersaction (allocates the matrix): {med * 1e3:8.1f} us median / {mn * 1e3:8.1f} min")
+    if n <= 10000:
+        orders = np.stack([np.random.default_rng(i).permutation(n) for i in range(3)])
+        med, mn = timed(lambda: fu.xie_propagation_points_in_order(pc, 0.1, orders, diffuse=False, knn_mask=-1, C=3), reps=5)
+        print(f"N={n:6d} ordered propagation, 3 orders: {med:8.2f} ms median = {med * 1e3 / n:.2f} us per step (matrix included)")
