@@ -50,6 +50,7 @@ __device__ inline double ieee_sqrt(double x) { return __builtin_sqrt(x); }
 #endif
 template <typename F>
 struct Recip {
+    static constexpr bool kShared = sizeof(F) == 4 && !DNP_XIE_IEEE_DIV;
     F b, r;
     __device__ explicit Recip(F den) : b(den), r(F(0)) {
         if constexpr (sizeof(F) == 4 && !DNP_XIE_IEEE_DIV) {
@@ -91,15 +92,23 @@ __global__ __launch_bounds__(kXieBlock) void xie_pairs_kernel(const XieArgs<F> a
         const F nrm = ieee_sqrt(rx * rx + ry * ry + rz * rz);
         // the quotients of the general case, computed for every lane (IEEE divisions: the reference's op order); a lane
         // with |R| == 0 - the diagonal of a self matrix - takes n_s instead: R_unit = 0 there and nothing is divided
-        const Recip<F> by_nrm(nrm);
-        const F ux = by_nrm.divide(rx), uy = by_nrm.divide(ry), uz = by_nrm.divide(rz);
-        const F d = a.C * (nx * ux + ny * uy + nz * uz);
         const F n3 = nrm * nrm * nrm;
-        const Recip<F> by_n3(n3);
         const bool coincident = nrm == F(0);
-        const F fx = coincident ? nx : by_n3.divide(nx - d * ux);
-        const F fy = coincident ? ny : by_n3.divide(ny - d * uy);
-        const F fz = coincident ? nz : by_n3.divide(nz - d * uz);
+        F ux, uy, uz, d, fx, fy, fz;
+        if (Recip<F>::kShared && !(nrm >= F(1e-10) && nrm <= F(1e10)) && !coincident) {
+            // |R| at an exponent extreme (never on a cloud in the unit box): |R|^3 may be denormal or overflow, where the
+            // compiler's division rescales its operands - take that division itself
+            ux = rx / nrm; uy = ry / nrm; uz = rz / nrm;
+            d = a.C * (nx * ux + ny * uy + nz * uz);
+            fx = (nx - d * ux) / n3; fy = (ny - d * uy) / n3; fz = (nz - d * uz) / n3;
+        } else {
+            const Recip<F> by_nrm(nrm), by_n3(n3);
+            ux = by_nrm.divide(rx); uy = by_nrm.divide(ry); uz = by_nrm.divide(rz);
+            d = a.C * (nx * ux + ny * uy + nz * uz);
+            fx = coincident ? nx : by_n3.divide(nx - d * ux);
+            fy = coincident ? ny : by_n3.divide(ny - d * uy);
+            fz = coincident ? nz : by_n3.divide(nz - d * uz);
+        }
         if constexpr (VEC) {
             po[0] = fx; po[1] = fy; po[2] = fz;
         } else {
