@@ -13,7 +13,10 @@
 //
 // xie_order: for each of R visiting orders, N sequential steps  inter[idx] = sum_j M[idx][j] * w[j];
 // w[idx] = inter[idx] < 0 ? -1 : +1  (w starts at 0, so only visited points contribute).  One persistent
-// workgroup per order: per step one coalesced read of a matrix row, an fp64 tree reduction and two barriers.
+// workgroup per order.  The order is GIVEN, so nothing but w[idx] links a step to the next: the weights live in registers
+// (thread t owns columns t, t + 1024, ...), the NEXT row is fetched while the current one is reduced, and every thread folds
+// the 16 wave partials itself - one barrier per step (round 3; up to 16 384 points, beyond that the plain form with the
+// weights in memory and two barriers).  Same products, same fp64 additions in the same order as the plain form.
 #include "dnp_common.h"
 
 #pragma clang fp contract(off)
@@ -151,6 +154,63 @@ __global__ __launch_bounds__(kOrderThreads) void xie_order_kernel(const float* _
     }
 }
 
+// VPT columns per thread (N <= 1024 * VPT)
+template <int VPT>
+__global__ __launch_bounds__(kOrderThreads) void xie_order_reg_kernel(const float* __restrict__ M, int64_t N,
+                                                                     const int64_t* __restrict__ order,
+                                                                     float* __restrict__ weights,
+                                                                     float* __restrict__ inter) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t* ord = order + (int64_t)blockIdx.x * N;
+    float* out = inter + (int64_t)blockIdx.x * N;
+    __shared__ double part[2][kOrderThreads / 64];
+    float w[VPT], cur[VPT], nxt[VPT];
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) { w[k] = 0.f; nxt[k] = 0.f; }
+    auto fetch = [&](int64_t idx, float (&dst)[VPT]) {
+        const float* row = M + idx * N;
+#pragma unroll
+        for (int k = 0; k < VPT; ++k) {
+            const int64_t j = tid + (int64_t)k * kOrderThreads;
+            dst[k] = row[j < N ? j : N - 1];              // clamped, unconditional: all VPT loads in flight at once
+        }
+    };
+    int64_t idx = ord[0];
+    fetch(idx, cur);
+    for (int64_t i = 0; i < N; ++i) {
+        const int64_t idx_next = i + 1 < N ? ord[i + 1] : idx;
+        if (i + 1 < N) fetch(idx_next, nxt);               // in flight while this row is reduced
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < VPT; ++k)
+            if (tid + (int64_t)k * kOrderThreads < N) s += (double)(cur[k] * w[k]);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        double* p = part[i & 1];
+        if (lane == 0) p[wave] = s;
+        __syncthreads();                                   // the only barrier of the step (partials double-buffered by parity)
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < kOrderThreads / 64; ++k) tot += p[k];
+        const float v = (float)tot;
+        const float sign = (v < 0.f) ? -1.f : 1.f;
+        if (tid == (int)(idx % kOrderThreads)) {
+            const int kk = (int)(idx / kOrderThreads);
+#pragma unroll
+            for (int k = 0; k < VPT; ++k) w[k] = (k == kk) ? sign : w[k];
+        }
+        if (tid == 0) out[idx] = v;
+#pragma unroll
+        for (int k = 0; k < VPT; ++k) cur[k] = nxt[k];
+        idx = idx_next;
+    }
+    float* wout = weights + (int64_t)blockIdx.x * N;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const int64_t j = tid + (int64_t)k * kOrderThreads;
+        if (j < N) wout[j] = w[k];
+    }
+}
+
 template <typename F>
 static int run_xie_pairs(const F* src, int64_t S, int64_t ld_src, const F* tgt, int64_t T, int64_t ld_tgt, F C,
                          int vector_out, F* out, hipStream_t stream) {
@@ -191,8 +251,18 @@ int dnp_xie_order_f32(const float* M, int64_t N, const int64_t* order, int64_t R
     DNP_REQUIRE(N >= 0 && R >= 0, "negative size");
     if (N == 0 || R == 0) return DNP_OK;
     DNP_REQUIRE(M && order && weights && inter, "NULL pointer");
-    hipLaunchKernelGGL(xie_order_kernel, dim3((unsigned)R), dim3(kOrderThreads), 0, (hipStream_t)stream, M, N, order,
-                       weights, inter);
+#ifndef DNP_XIE_ORDER_PLAIN      // A/B builds: the plain form for every size
+#define DNP_XIE_ORDER_PLAIN 0
+#endif
+    if (!DNP_XIE_ORDER_PLAIN && N <= 4 * kOrderThreads)
+        hipLaunchKernelGGL(xie_order_reg_kernel<4>, dim3((unsigned)R), dim3(kOrderThreads), 0, (hipStream_t)stream, M, N, order,
+                           weights, inter);
+    else if (!DNP_XIE_ORDER_PLAIN && N <= 16 * kOrderThreads)
+        hipLaunchKernelGGL(xie_order_reg_kernel<16>, dim3((unsigned)R), dim3(kOrderThreads), 0, (hipStream_t)stream, M, N, order,
+                           weights, inter);
+    else
+        hipLaunchKernelGGL(xie_order_kernel, dim3((unsigned)R), dim3(kOrderThreads), 0, (hipStream_t)stream, M, N, order,
+                           weights, inter);
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
 }

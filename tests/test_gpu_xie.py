@@ -171,3 +171,50 @@ def test_xie_pairs_are_the_ieee_op_order_bit_for_bit(dev, scale):
         got_m = fu.xie_intersaction(src, tgt, eps=0.1, knn_mask=-1, C=C)
         assert torch.equal(got_f, want_f), float((got_f - want_f).abs().max())
         assert torch.equal(got_m, want_m), float((got_m - want_m).abs().max())
+
+
+def _order_kernel_spec(M, order):
+    """dnp_xie_order_f32 as specified (csrc/dnp_xie.hip): fp32 products, fp64 sums - thread t of 1024 adds its columns
+    t, t + 1024, ... in ascending order, each wavefront folds its 64 sums by halving (lane l += lane l + off, off = 32 ... 1),
+    the 16 wavefront sums are added in wavefront order - and the sign of the rounded fp32 total becomes the weight."""
+    N = M.shape[0]
+    pad = -(-N // 1024) * 1024
+    w = np.zeros(N, dtype=np.float32)
+    inter = np.zeros(N, dtype=np.float32)
+    for idx in order:
+        p = np.zeros(pad, dtype=np.float64)
+        p[:N] = (M[idx] * w).astype(np.float32)
+        s = np.zeros(1024)
+        for k in range(pad // 1024):
+            s = s + p[k * 1024:(k + 1) * 1024]
+        v = s.reshape(16, 64).copy()
+        for off in (32, 16, 8, 4, 2, 1):
+            v[:, :off] = v[:, :off] + v[:, off:2 * off]
+        tot = 0.0
+        for k in range(16):
+            tot = tot + v[k, 0]
+        inter[idx] = np.float32(tot)
+        w[idx] = -1.0 if inter[idx] < 0 else 1.0
+    return inter, w
+
+
+@pytest.mark.parametrize("n", [700, 1500, 5000])
+def test_xie_order_kernel_is_its_specification_bit_for_bit(dev, n):
+    """The register-resident, row-prefetching forms of the ordered propagation (round 3: 4 and 16 columns per thread)
+    against the summation order they are specified to keep - inter and weights bit for bit, two orders at once."""
+    from dipole_normal_prop_amd import _lib
+    lib = _lib.require_device()
+    gen = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 6, generator=gen)
+    pc = torch.cat([x[:, :3], torch.nn.functional.normalize(x[:, 3:], dim=1)], 1).to(dev)
+    M = fu.xie_intersaction(pc, pc, 0.1, -1, 3).contiguous()
+    orders = np.stack([np.random.default_rng(s).permutation(n) for s in (1, 2)]).astype(np.int64)
+    order_t = t(orders).to(dev)
+    weights = torch.full((2, n), 7.0, dtype=torch.float32, device=dev)
+    inter = torch.full((2, n), 7.0, dtype=torch.float32, device=dev)
+    assert lib.dnp_xie_order_f32(_lib.ptr(M), n, _lib.ptr(order_t), 2, _lib.ptr(weights), _lib.ptr(inter), _lib.current_stream()) == 0
+    Mh = M.cpu().numpy()
+    for r in range(2):
+        want_i, want_w = _order_kernel_spec(Mh, orders[r])
+        assert np.array_equal(inter[r].cpu().numpy(), want_i)
+        assert np.array_equal(weights[r].cpu().numpy(), want_w)

@@ -23,6 +23,12 @@ if not os.path.exists(IEEE):
     build.build(extra_flags=["-DDNP_XIE_IEEE_DIV=1"], out=IEEE, verbose=False)
 ieee = ctypes.CDLL(IEEE)
 ieee.dnp_xie_pairs_f32.restype, ieee.dnp_xie_pairs_f32.argtypes = _lib.SIGNATURES["dnp_xie_pairs_f32"]
+PLAIN = os.path.join(ROOT, "tools", "bin", "libdnp_xie_plain.so")
+if not os.path.exists(PLAIN):
+    from dipole_normal_prop_amd import build
+    build.build(extra_flags=["-DDNP_XIE_ORDER_PLAIN=1"], out=PLAIN, verbose=False)
+plain = ctypes.CDLL(PLAIN)
+plain.dnp_xie_order_f32.restype, plain.dnp_xie_order_f32.argtypes = _lib.SIGNATURES["dnp_xie_order_f32"]
 
 
 def timed(fn, reps=20):
@@ -62,3 +68,15 @@ for n in (4000, 10000, 16000):
         orders = np.stack([np.random.default_rng(i).permutation(n) for i in range(3)])
         med, mn = timed(lambda: fu.xie_propagation_points_in_order(pc, 0.1, orders, diffuse=False, knn_mask=-1, C=3), reps=5)
         print(f"N={n:6d} ordered propagation, 3 orders: {med:8.2f} ms median = {med * 1e3 / n:.2f} us per step (matrix included)")
+        M = fu.xie_intersaction(pc, pc, 0.1, -1, 3).contiguous()
+        ot = torch.from_numpy(orders.astype(np.int64)).to(dev)
+        wts, itr = torch.empty((3, n), device=dev), torch.empty((3, n), device=dev)
+        res = {}
+        for name, L in (("product (weights in registers, next row prefetched, one barrier)", lib), ("plain (-DDNP_XIE_ORDER_PLAIN=1)", plain)):
+            L.dnp_xie_order_f32(_lib.ptr(M), n, _lib.ptr(ot), 3, _lib.ptr(wts), _lib.ptr(itr), stream)
+            torch.cuda.synchronize()
+            res[name] = (wts.clone(), itr.clone())
+            med, mn = timed(lambda: L.dnp_xie_order_f32(_lib.ptr(M), n, _lib.ptr(ot), 3, _lib.ptr(wts), _lib.ptr(itr), stream), reps=5)
+            print(f"N={n:6d}   dnp_xie_order_f32 {name}: {mn:8.3f} ms = {mn * 1e3 / n:.2f} us per step")
+        (w1, i1), (w2, i2) = res.values()
+        print(f"N={n:6d}   weights and interactions bit-identical between the two forms: {bool(torch.equal(w1, w2) and torch.equal(i1, i2))}")
