@@ -3,10 +3,6 @@
 // (field_utils.strongest_field_propagation{,_reps}, field_utils.py:207-348).
 #include <math.h>
 
-#ifdef DNP_TAIL_BEHIND
-#include <hip/hip_ext.h>
-#endif
-
 #include "dnp_common.h"
 #include "pair_kernel.h"
 
@@ -203,44 +199,13 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts, cons
                                       p_end, eps, dE, nullptr, 1, stream);
 }
 
-// behind: dispatch the launch BEHIND the previous one of the stream without a barrier (hipExtAnyOrderLaunch): its
-// workgroups start as soon as the previous launch has none left to start, while that launch's last workgroups still run.
-static int patch_fields_tiled(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
-                              const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
-                              const float* patch_box, const float* tile_box, int64_t p_begin, int64_t p_end, float eps,
-                              float* dE, double* w_part, int source_split, bool behind, void* stream);
-
 int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
                                const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
                                const float* patch_box, const float* tile_box, int64_t p_begin, int64_t p_end, float eps,
                                float* dE, double* w_part, int source_split, void* stream) {
     clear_error();
-#ifdef DNP_TAIL_BEHIND   // experiment builds only (tools/gpu_tail_fill.py, profiles/r03_tail_fill.txt: the flag is not honoured on gfx9)
-    if (source_split < 0) {
-        // -k: the last k patches of the range as a second launch with source_split 4 (items a third as long, the same
-        // bits) dispatched behind the first without a barrier - the short items flow in when the long ones run out
-        DNP_REQUIRE(source_split >= -65535, "source_split=%d", source_split);
-        DNP_REQUIRE(N >= 0 && 0 <= p_begin && p_begin <= p_end && p_end <= P, "bad patch range");
-        const int64_t K = p_end - p_begin, k = -source_split < K ? -source_split : K;
-        DNP_REQUIRE(K <= 65535, "the tail form takes one launch slice (65535 patches)");
-        const int64_t n_tiles = ceil_div(N, (int64_t)64 * kPatchScalarKT);
-        int rc = patch_fields_tiled(pts, N, ld_pts, patch_off, patch_idx, P, point_patch, patch_box, tile_box, p_begin,
-                                    p_end - k, eps, dE, w_part, 1, false, stream);
-        if (rc != DNP_OK) return rc;
-        return patch_fields_tiled(pts, N, ld_pts, patch_off, patch_idx, P, point_patch, patch_box, tile_box, p_end - k, p_end,
-                                  eps, dE + (K - k) * N * 3, w_part ? w_part + (K - k) * n_tiles * 2 : nullptr, 4,
-                                  /*behind=*/K - k > 0, stream);
-    }
-#endif
-    return patch_fields_tiled(pts, N, ld_pts, patch_off, patch_idx, P, point_patch, patch_box, tile_box, p_begin, p_end, eps,
-                              dE, w_part, source_split, false, stream);
-}
-
-static int patch_fields_tiled(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
-                              const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
-                              const float* patch_box, const float* tile_box, int64_t p_begin, int64_t p_end, float eps,
-                              float* dE, double* w_part, int source_split, bool behind, void* stream) {
-    DNP_REQUIRE(source_split == 1 || source_split == 4, "source_split=%d (1 or 4)", source_split);
+    DNP_REQUIRE(source_split == 1 || source_split == 4 || (source_split < 0 && source_split >= -65535),
+                "source_split=%d (1, 4, or -k: the last k patches split)", source_split);
     DNP_REQUIRE(N >= 0 && P >= 0, "negative size");
     DNP_REQUIRE(0 <= p_begin && p_begin <= p_end && p_end <= P, "bad patch range [%lld,%lld) of %lld",
                 (long long)p_begin, (long long)p_end, (long long)P);
@@ -269,23 +234,34 @@ static int patch_fields_tiled(const float* pts, int64_t N, int64_t ld_pts, const
         if (scalar_path) {
             // patch-sorted cloud (what the drivers pass): contiguous sources -> the scalar-unit kernel
             const bool tabled = patch_box && tile_box && kPatchFar && pa.far_d2 > 0.f;
-            const int ss = tabled ? source_split : 1;        // the source split exists for the fully tabled form only
+            // the source split exists for the fully tabled form only; -k (the last k patches of the launch split, ONE launch:
+            // pair_kernel.h TAIL) needs the whole range in this slice and at least one unsplit patch
+            const int tail = (tabled && source_split < 0 && k0 == 0 && kn == K && -source_split < K) ? -source_split : 0;
+            int ss = 1;
+            if (tabled && source_split > 0) ss = source_split;
+            else if (tabled && !tail && -source_split >= K) ss = 4;     // -k with k >= the whole range: every patch split
             // the tabled, unsplit form runs in workgroups of kTabledWaves wavefronts (pair_kernel.h, WAVES)
             const int waves = (tabled && ss == 1) ? kTabledWaves : kBlock / 64;
             const dim3 sgrid((unsigned)ceil_div(N, (int64_t)(waves / ss) * 64 * kPatchScalarKT), (unsigned)kn);
             pa.chunk_box = patch_box;
             pa.tile_box = tile_box;
             pa.w_part = w_part ? w_part + k0 * ceil_div(N, (int64_t)64 * kPatchScalarKT) * 2 : nullptr;
-#ifdef DNP_TAIL_BEHIND
-#define DNP_LAUNCH_TABLED(WP, SS, WV)                                                                                    \
-    hipExtLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, WP, SS, WV>), \
-                          sgrid, dim3(WV * 64), 0, st, nullptr, nullptr, behind ? hipExtAnyOrderLaunch : 0, pa)
-#else
 #define DNP_LAUNCH_TABLED(WP, SS, WV)                                                                                    \
     hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, WP, SS, WV>), \
                        sgrid, dim3(WV * 64), 0, st, pa)
-#endif
-            if (tabled && w_part) {
+            if (tail) {
+                const int64_t n_tiles = ceil_div(N, (int64_t)64 * kPatchScalarKT);
+                const int64_t blocks = (K - tail) * ceil_div(n_tiles, (int64_t)4) + (int64_t)tail * n_tiles;
+                DNP_REQUIRE(blocks < ((int64_t)1 << 31), "the tail form's grid of %lld workgroups", (long long)blocks);
+                pa.split_from = (int)(K - tail);
+                const dim3 tgrid((unsigned)blocks);
+                if (w_part)
+                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, true, 4, 4, true>),
+                                       tgrid, dim3(256), 0, st, pa);
+                else
+                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, false, 4, 4, true>),
+                                       tgrid, dim3(256), 0, st, pa);
+            } else if (tabled && w_part) {
                 if (ss == 4) DNP_LAUNCH_TABLED(true, 4, 4);
                 else DNP_LAUNCH_TABLED(true, 1, kTabledWaves);
             } else if (tabled) {

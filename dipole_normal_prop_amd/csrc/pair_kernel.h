@@ -147,6 +147,7 @@ struct PairArgs {
     F far_d2;                // scalar kernel, FAR: squared box distance beyond which the one-transcendental chain runs
     const F* tile_box;       // scalar kernel, TBOX: [ceil(T / (64 KT))][6] boxes of the wavefronts' target tiles (dnp_tile_boxes_f32)
     double* w_part;          // scalar kernel, WPART: [gridDim.y][ceil(T / (64 KT))][2] per-(slab, tile) interaction partials
+    int split_from;          // scalar kernel, TAIL: chunks [split_from, n) of the launch are evaluated with the source split
     int32_t chunk_off[kMaxChunks + 1];  // by-value CSR offsets when chunk_off_dev == nullptr
 };
 
@@ -567,7 +568,7 @@ __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, cons
 // wavefronts measured 4.049 ms on the bench launch against 4.074 with 4 (a CU takes a new pair of wavefronts as soon as
 // two slots are free) and 4.060 with 1 (profiles/r03_ab_block.txt).  SS > 1 needs WAVES = 4.
 template <typename F, typename PT, int MODE, int KT, int V, bool FAR = false, bool BOX = false, bool TBOX = false,
-          bool WPART = false, int SS = 1, int WAVES = kBlock / 64>
+          bool WPART = false, int SS = 1, int WAVES = kBlock / 64, bool TAIL = false>
 __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<F, PT> a) {
     using M = Math<F>;
     constexpr int NC = (MODE == kField) ? 3 : 1;
@@ -576,21 +577,14 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
     static_assert(SS == 1 || MODE == kField, "the source split is built for the field mode");
     static_assert(WAVES % SS == 0 && WAVES >= SS, "a workgroup holds whole target tiles");
     constexpr int kTG = WAVES / SS;                         // target tiles per workgroup
+    static_assert(!TAIL || (SS == 4 && WAVES == 4 && BOX && TBOX && sizeof(PT) == 4), "TAIL: the tabled patch-mode split kernel");
     DNP_STAMP_BEGIN_SCALAR();
     __shared__ F chunk_box[WAVES][6];
     __shared__ double split_terms[SS > 1 ? SS - 1 : 1][SS > 1 ? kTG : 1][KT][SS > 1 ? NC : 1][SS > 1 ? 64 : 1];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // an SGPR: everything derived from it stays wave-uniform,
-    const int tg = wave / SS, sp = wave % SS;               // above all the source range (scalar loads); tile / source part
-    const int64_t chunk = blockIdx.y;
-    int64_t s_begin, s_end;
-    if (a.chunk_off_dev) {
-        s_begin = a.chunk_off_dev[a.chunk_base + chunk];
-        s_end = a.chunk_off_dev[a.chunk_base + chunk + 1];
-    } else {
-        s_begin = a.chunk_off[chunk];
-        s_end = a.chunk_off[chunk + 1];
-    }
+    int tg = wave / SS, sp = wave % SS;                     // above all the source range (scalar loads); tile / source part
+    int64_t chunk = blockIdx.y;
     // XCD-aware tile mapping.  Workgroups are dealt round-robin over the 8 XCDs in launch order (x fastest: XCD = linear
     // id mod 8 - observed behaviour, MI355X_MICROARCH.md; only speed depends on it).  With a grid width that is not a
     // multiple of 8 a target tile would wander over the XCDs from one chunk row to the next, and every XCD's L2 would
@@ -601,8 +595,45 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
 #define DNP_XCD_MAP 1
 #endif
     unsigned bx = blockIdx.x;
-    if (DNP_XCD_MAP && bx < (gridDim.x & ~7u)) bx = (bx & ~7u) | ((bx + blockIdx.y * gridDim.x) & 7u);
-    const int64_t tile_base = (int64_t)bx * (kTG * 64 * KT);
+    // TAIL: ONE launch whose last chunks are split - a 1-D grid, first the chunks [0, split_from) with a workgroup's four
+    // wavefronts on four target tiles (the SS = 1 form: every wavefront runs the whole chunk), then the chunks from
+    // split_from on with the four wavefronts on ONE tile (the SS = 4 form).  Workgroups start in grid order, so the
+    // launch's last resident set consists of items a third as long and the chip drains in a third of the time
+    // (profiles/r03_timeline.txt: 49 us of a 0.56 ms launch were drain); the bits are those of either form.
+    bool row_split = SS > 1;
+    int ktg = kTG;                                           // target tiles of this workgroup
+    if constexpr (TAIL) {
+        const unsigned n_tiles = (unsigned)((a.T + 64 * KT - 1) / (64 * KT));
+        const unsigned gxa = (n_tiles + WAVES - 1) / WAVES;
+        const unsigned unsplit_blocks = (unsigned)a.split_from * gxa;
+        const unsigned b = blockIdx.x;
+        if (b < unsplit_blocks) {
+            const unsigned row = b / gxa;
+            bx = b - row * gxa;
+            if (DNP_XCD_MAP && bx < (gxa & ~7u)) bx = (bx & ~7u) | ((bx + row * gxa) & 7u);
+            chunk = row;
+            row_split = false;
+            ktg = WAVES;
+            tg = wave;
+            sp = 0;
+        } else {
+            const unsigned c = b - unsplit_blocks;
+            const unsigned row = c / n_tiles;
+            bx = c - row * n_tiles;
+            chunk = (int64_t)a.split_from + row;
+        }
+    } else {
+        if (DNP_XCD_MAP && bx < (gridDim.x & ~7u)) bx = (bx & ~7u) | ((bx + blockIdx.y * gridDim.x) & 7u);
+    }
+    int64_t s_begin, s_end;
+    if (a.chunk_off_dev) {
+        s_begin = a.chunk_off_dev[a.chunk_base + chunk];
+        s_end = a.chunk_off_dev[a.chunk_base + chunk + 1];
+    } else {
+        s_begin = a.chunk_off[chunk];
+        s_end = a.chunk_off[chunk + 1];
+    }
+    const int64_t tile_base = (int64_t)bx * (ktg * 64 * KT);
     F tx[KT], ty[KT], tz[KT];
     int64_t trow[KT];
 #pragma unroll
@@ -668,7 +699,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
             // entry for them either - round 3's first form read up to 72 bytes past its end, found by tools/gpu_fuzz.py
             // as a memory access fault when the table ended on a page boundary)
             const int64_t n_tiles = (a.T + 64 * KT - 1) / (64 * KT);
-            int64_t wave_tile = (int64_t)bx * kTG + __builtin_amdgcn_readfirstlane(tg);
+            int64_t wave_tile = (int64_t)bx * ktg + __builtin_amdgcn_readfirstlane(tg);
             wave_tile = wave_tile < n_tiles ? wave_tile : n_tiles - 1;
             const F* tb = a.tile_box + wave_tile * 6;                       // wave-uniform: scalar loads
 #pragma unroll
@@ -753,7 +784,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
         s = part_lo;
         part_end = part_hi;
     } else if constexpr (SS > 1) {
-        exchange = (s_end - s_begin) <= (int64_t)SS * run_len;
+        exchange = row_split && (s_end - s_begin) <= (int64_t)SS * run_len;
         if (exchange) {
             s = s_begin + (int64_t)sp * run_len;
             part_end = (s + run_len < s_end) ? s + run_len : s_end;
@@ -797,7 +828,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
                                           : (double)(P[0][k] + P[1][k]);
         }
     }
-    if constexpr (SS > 1) {
+    if (SS > 1 && row_split) {
         // run i's term travels on its own and part 0 adds the terms in run order: exactly the sums of the SS = 1 form
         if (exchange && sp != 0) {
 #pragma unroll
@@ -868,7 +899,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
             w_other += __shfl_xor(w_other, off, 64);
         }
         const int64_t n_tiles = (a.T + 64 * KT - 1) / (64 * KT);
-        const int64_t wave_tile = (int64_t)bx * kTG + tg;
+        const int64_t wave_tile = (int64_t)bx * ktg + tg;
         if ((tid & 63) == 0 && wave_tile < n_tiles) {
             double* wp = a.w_part + ((int64_t)chunk * n_tiles + wave_tile) * 2;
             wp[0] = w_first;

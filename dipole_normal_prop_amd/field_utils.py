@@ -616,22 +616,25 @@ class _TileTables:
         self.fused = _tiles_within_two_groups(sizes, N, self.rows)
 
 
-# Source split of the pair kernel's work items (include/dnp.h, dnp_patch_fields_tiled_f32): launches below this pair
-# count run with the four wavefronts of a workgroup on ONE target tile, one 128-source run of the patch each.  A launch
-# ends with tens of microseconds of a chip that is emptying, and that tail scales with the item length; shorter items
-# cost more prologues, and with runs of 128 a 390-point patch leaves the fourth wavefront almost idle: measured on the
-# 100 000-point sphere 16 patches per launch 0.350 -> 0.319 ms, 32 patches 0.568 -> 0.586 (tools/gpu_item_size.py,
-# profiles/r03_item_size.txt, r03_ab_source_split.txt).  Results do not depend on the choice (bit-identical slabs
-# and partials).
-SPLIT4_BELOW_PAIRS = 8.0e8
+# Source split of the pair kernel's work items (include/dnp.h, dnp_patch_fields_tiled_f32).  A launch ends with ~50 us of a
+# chip that is emptying, and that tail scales with the item length (profiles/r03_timeline.txt); with the four wavefronts
+# of a workgroup on ONE target tile, one 128-source run of the patch each, an item is a third as long - at the price of
+# more prologues and an almost idle fourth wavefront (a 390-point patch is 128 + 128 + 128 + 6).  So only the LAST
+# patches of a launch are split (source_split = -k: one launch, its last resident set made of short items), and only
+# for launches short enough for the tail to matter: 100 000-point sphere, ms per launch unsplit / all split / last 3 split
+# (tools/gpu_tail_fill.py, profiles/r03_tail_fill.txt): 4 patches 0.116 / 0.099 / 0.092, 16 patches 0.309 / 0.299 / 0.287,
+# 32 patches (a rank's share of 8) 0.560 / 0.578 / 0.552, 48 patches 0.808 / 0.853 / 0.812.  Results do not depend on
+# the choice (bit-identical slabs and partials).
+TAIL_BELOW_PAIRS = 1.7e9
+TAIL_PATCHES = 3
 
 
 def _pick_source_split(sizes_block: np.ndarray, n_targets: int) -> int:
-    """1 or 4 for a launch over patches of these sizes: 4 only when every patch has 2..4 runs of 128 sources
-    (129..512 points) and the launch is short."""
+    """source_split for a launch over patches of these sizes: 1, or -TAIL_PATCHES (the last patches split) when the
+    launch is short and every patch has 2..4 runs of 128 sources (129..512 points)."""
     if len(sizes_block) == 0 or int(sizes_block.min()) <= 128 or int(sizes_block.max()) > 512:
         return 1
-    return 4 if float(sizes_block.sum()) * float(n_targets) < SPLIT4_BELOW_PAIRS else 1
+    return -TAIL_PATCHES if float(sizes_block.sum()) * float(n_targets) < TAIL_BELOW_PAIRS else 1
 
 
 def _slabs_and_rows(swork, off, point_patch, b0: int, b1: int, eps: float, boxes, tiles: "_TileTables", sizes=None):

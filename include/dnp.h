@@ -166,12 +166,15 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts,
  *     fixed order).  With every tile inside at most two groups (patches of >= R points; rows in no patch last) W follows
  *     from dnp_interactions_from_tiles without a second pass over the 12 N P bytes of slabs; the caller checks that
  *     condition (the drivers do, on the host, from the patch sizes) and uses dnp_interactions_f32 otherwise.
- * source_split (1 or 4; used with both tables only): with 4 the four wavefronts of a workgroup share ONE target tile and
- * wavefront i evaluates the patch's i-th run of 128 sources (the run terms meet in LDS and are added in run order):
- * work items up to four times shorter, for SHORT launches - see profiles/r03_item_size.txt.  dE and w_part do not
- * depend on source_split (the same fp32 runs, the same fp64 additions); patches of more than 512 points are evaluated
- * by one wavefront per tile whatever source_split says, patches of <= 128 points are a single run - so 4 pays only
- * when the patches of the range have 129..512 points (the drivers check that, and use it below 8 10^8 pairs).
+ * source_split (1, 4 or -k; used with both tables only): with 4 the four wavefronts of a workgroup share ONE target tile
+ * and wavefront i evaluates the patch's i-th run of 128 sources (the run terms meet in LDS and are added in run order):
+ * work items up to four times shorter.  -k (k >= 1): ONE launch in which only the LAST k patches of the range are split
+ * that way (k >= the range: all of them) - the launch's last resident set then consists of short items and the chip
+ * drains in a third of the time, while the other patches keep the unsplit form's efficiency; this is what the drivers
+ * use, with k = 3, for launches below 1.7 10^9 pairs (profiles/r03_tail_fill.txt, r03_timeline.txt).  dE and w_part do
+ * not depend on source_split (the same fp32 runs, the same fp64 additions); patches of more than 512 points are
+ * evaluated by one wavefront per tile whatever source_split says, patches of <= 128 points are a single run - so a
+ * split pays only when the patches have 129..512 points (the drivers check that).
  * dE is bit-identical with dnp_patch_fields_boxed_f32's; w_part requires eps >= 1e-30 and both tables.
  */
 int64_t dnp_patch_tile_rows(void);

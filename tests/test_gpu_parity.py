@@ -423,7 +423,8 @@ def test_tile_tables_and_fused_interaction_rows(dev):
 
 def test_source_split_does_not_change_a_bit(dev):
     """dnp_patch_fields_tiled_f32's source_split = 4 (the four wavefronts of a workgroup on one target tile, one
-    128-source run of the patch each, run terms through LDS, added in run order) against 1: slabs and interaction
+    128-source run of the patch each, run terms through LDS, added in run order) and -k (one launch whose last k patches
+    are split, the others not) against 1: slabs and interaction
     partials bit-identical - on the headline cloud's patches (all of 129..512 points) and on a cut with patches
     outside that window (<= 128 points: a single run; > 512: one wavefront evaluates them whatever the split) - and
     the split-4 slabs agree with the fp64 oracle.  The drivers' rule picks 4 for short launches only."""
@@ -435,13 +436,14 @@ def test_source_split_does_not_change_a_bit(dev):
     assert sizes.min() > 128 and sizes.max() <= 512
     point_patch = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
     boxes, tiles = fu._patch_boxes(swork, off, None), fu._TileTables(swork, sizes)
-    assert fu._pick_source_split(sizes[:16], N) == 4 and fu._pick_source_split(sizes[:32], N) == 1 and fu._pick_source_split(sizes, N) == 1
+    assert fu._pick_source_split(sizes[:16], N) == -3 and fu._pick_source_split(sizes[:32], N) == -3 and fu._pick_source_split(sizes, N) == 1
     assert fu._pick_source_split(np.array([100, 300]), N) == 1 and fu._pick_source_split(np.array([300, 600]), N) == 1
     res = {}
-    for ss in (1, 4):
+    for ss in (1, 4, -1, -3, -7, -23, -24, -100):         # -k: ONE launch whose last k patches are split (k >= 24: all of them)
         wp = torch.zeros((24, tiles.n_tiles, 2), dtype=torch.float64, device=dev)
         res[ss] = (fu._patch_slabs(swork, off, None, point_patch, 40, 64, 1e-5, boxes, tiles.boxes, wp, ss), wp)
-    assert torch.equal(res[1][0], res[4][0]) and torch.equal(res[1][1], res[4][1])
+        assert torch.equal(res[1][0], res[ss][0]) and torch.equal(res[1][1], res[ss][1]), ss
+        assert torch.equal(fu._patch_slabs(swork, off, None, point_patch, 40, 64, 1e-5, boxes, tiles.boxes, None, ss), res[1][0]), ss
     k = 51
     others = (point_patch != k).cpu()
     rows = torch.nonzero(others).flatten()[::53]
@@ -459,6 +461,8 @@ def test_source_split_does_not_change_a_bit(dev):
     a = fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, None, 1)
     b = fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, None, 4)
     assert torch.equal(a, b)
+    for tail in (-1, -2, -4, -9):
+        assert torch.equal(a, fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, None, tail)), tail
     for k in (1, 2, 5, 9):
         lo, hi = int(off2[k]), int(off2[k + 1])
         others = (pp2 != k).cpu()

@@ -18,7 +18,6 @@ from tools.workloads import headline_workload  # noqa: E402
 
 dev = torch.device("cuda:0")
 lib = _lib.require_device()
-BEHIND = os.path.join(ROOT, "tools", "bin", "libdnp_tailbehind.so")      # -DDNP_TAIL_BEHIND=1: source_split = -k
 pc, patches, _ = headline_workload()
 off, idx, sizes = util.patch_csr(patches, dev)
 pts = pc.to(dev)[idx].contiguous()
@@ -55,7 +54,7 @@ def timed(fn, reps=40):
     return float(np.median(ts)), float(np.min(ts))
 
 
-for K in (32, 256):
+for K in ((32, 256) if os.environ.get("TAIL_FILL_STREAMS") else ()):      # the two-stream form: TAIL_FILL_STREAMS=1
     print(f"K={K}: single launch {timed(lambda: launch(0, K, 1, main))}")
     for k in (2, 4, 8):
         for label, hi_s, lo_s in (("main=normal, tail=low", main, side), ("main=high, tail=normal", fast, side)):
@@ -75,27 +74,23 @@ for K in (32, 256):
                     main.wait_event(e2)
             print(f"   last {k} patches split x4 on a second stream ({label}): {timed(both)}")
 
-# Second form (same round): ONE stream, the tail launch dispatched BEHIND the main launch without a barrier
-# (dnp_patch_fields_tiled_f32 source_split = -k -> hipExtAnyOrderLaunch): the command processor starts the tail's
-# workgroups when the main launch has none left to start.
-print("# tail launch behind the main launch on the same stream, no barrier (source_split = -k); interleaved with the single launch")
-if not os.path.exists(BEHIND):
-    from dipole_normal_prop_amd import build
-    build.build(extra_flags=["-DDNP_TAIL_BEHIND=1"], out=BEHIND, verbose=False)
-lib = ctypes.CDLL(BEHIND)
-lib.dnp_patch_fields_tiled_f32.restype, lib.dnp_patch_fields_tiled_f32.argtypes = _lib.SIGNATURES["dnp_patch_fields_tiled_f32"]
-for K in (16, 32, 64, 256):
+# (A second form - the tail launch dispatched BEHIND the main launch in the same stream without a barrier, hipExtAnyOrderLaunch -
+# was measured with an experiment build of this round and removed again: gfx9 keeps the barrier; profiles/r03_tail_fill.txt.)
+# Third form, the one that shipped: ONE launch whose last k patches are split (source_split = -k, pair_kernel.h TAIL).
+print("# one launch, the last k patches split (source_split = -k); interleaved with the plain launch and the all-split launch")
+for K in (4, 8, 12, 16, 24, 32, 40, 48, 64, 128, 256):
     launch(0, K, 1, main)
     torch.cuda.synchronize()
     ref, wref = dE[:K].clone(), wp[:K].clone()
-    line = f"K={K}: single {timed(lambda: launch(0, K, 1, main))}"
-    for k in (1, 2, 3, 4, 6, 8, 12):
+    line = f"K={K}: split 1 {timed(lambda: launch(0, K, 1, main), reps=30)[0]:.4f}  split 4 {timed(lambda: launch(0, K, 4, main), reps=30)[0]:.4f}"
+    for k in (1, 2, 3, 4, 6, 8):
         if k >= K:
             continue
         dE[:K].zero_()
+        wp[:K].zero_()
         launch(0, K, -k, main)
         torch.cuda.synchronize()
         same = bool(torch.equal(dE[:K], ref)) and bool(torch.equal(wp[:K], wref))
-        line += f"   -{k}: {timed(lambda: launch(0, K, -k, main), reps=30)}{'' if same else ' RESULTS DIFFER'}"
-    line += f"   single again {timed(lambda: launch(0, K, 1, main))}"
+        line += f"  -{k}: {timed(lambda: launch(0, K, -k, main), reps=30)[0]:.4f}{'' if same else ' RESULTS DIFFER'}"
+    line += f"  split 1 again {timed(lambda: launch(0, K, 1, main), reps=30)[0]:.4f}"
     print(line, flush=True)
