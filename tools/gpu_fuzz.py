@@ -69,7 +69,8 @@ def run(budget=180.0, seed=0):
     fails, cases = [], 0
     t_end = time.time() + budget
     t_note = time.time() + 60.0
-    while time.time() < t_end:
+    stop_at = int(os.environ.get("FUZZ_STOP_CASE", "0"))
+    while time.time() < t_end and not (stop_at and cases >= stop_at):
         if time.time() > t_note:                             # a sign of life once a minute (long runs under gpurun)
             print(f"  ... {cases} cases, {len(fails)} failures", flush=True)
             t_note = time.time() + 60.0
@@ -209,8 +210,22 @@ def run(budget=180.0, seed=0):
                 tgt[:, :3] += 0.37                            # keep targets off the sources: the potential has no eps
                 phi = fu.potential(src.to(dev), tgt.to(dev)).cpu().numpy().astype(np.float64)
                 ref = c_oracle.potential_f64(src.numpy(), tgt.numpy())
-                if np.abs(phi - ref).max() > 1e-5 * max(np.abs(ref).max(), 1e-30):
-                    fails.append(f"case {cases}: potential {S}x{T} off by {np.abs(phi - ref).max() / np.abs(ref).max():.2e}")
+                # fp32 terms n.r / |r|^3 carry 6e-8 |n||r| of rounding in n.r whatever its own size: the same 16 u sum-of-|term|
+                # allowance as for the field rows (seed 2025 met a near-perpendicular close pair: 1.6e-5 of max |phi| without it)
+                rr = src.numpy()[None, :, :3].astype(np.float64) - tgt.numpy()[:, None, :3].astype(np.float64)
+                dd = np.linalg.norm(rr, axis=-1)
+                allow = 16 * 6e-8 * np.where(dd > 0, np.linalg.norm(src.numpy()[None, :, 3:], axis=-1) / np.maximum(dd, 1e-300) ** 2, 0).sum(axis=1)
+                err = np.maximum(np.abs(phi - ref) - allow, 0)
+                if os.environ.get("FUZZ_DETAIL_CASE") == str(cases):      # replay of a reported case: what the numbers are
+                    from oracle import dipole_oracle as O
+                    cpu32 = O.potential(src, tgt).numpy().astype(np.float64)
+                    i = int(np.argmax(np.abs(phi - ref)))
+                    print(f"  detail case {cases}: max |phi64| {np.abs(ref).max():.4e}; worst target {i}: phi64 {ref[i]:.6e}, HIP error "
+                          f"{abs(phi[i] - ref[i]):.3e}, reference-class torch fp32 error there {abs(cpu32[i] - ref[i]):.3e} (its own max "
+                          f"{np.abs(cpu32 - ref).max():.3e}), closest source at {dd[i].min():.3e}, sum of |term| bounds {allow[i] / (16 * 6e-8):.4e}, "
+                          f"allowance {allow[i]:.3e}", flush=True)
+                if err.max() > 1e-5 * max(np.abs(ref).max(), 1e-30):
+                    fails.append(f"case {cases}: potential {S}x{T} off by {err.max() / np.abs(ref).max():.2e} beyond the term allowance")
             elif kind == 6:                                  # per-point driver, both forms: a complete visit order, forms agree
                 N = int(rng.integers(2, 260))
                 pc = cloud(N)
