@@ -80,8 +80,17 @@ static void run_blocks(int64_t blocks, Fn&& fn) {
     if (blocks <= 1) { fn((int64_t)0); return; }
     std::vector<std::thread> pool;
     pool.reserve((size_t)blocks - 1);
-    for (int64_t b = 1; b < blocks; ++b) pool.emplace_back([&fn, b] { fn(b); });
+    int64_t inline_from = blocks;                       // blocks [inline_from, blocks) run here when no thread could be started
+    for (int64_t b = 1; b < blocks; ++b) {
+        try {
+            pool.emplace_back([&fn, b] { fn(b); });
+        } catch (...) {                                  // std::system_error (thread limit): nothing may leave an extern "C" entry
+            inline_from = b;
+            break;
+        }
+    }
     fn((int64_t)0);
+    for (int64_t b = inline_from; b < blocks; ++b) fn(b);
     for (auto& t : pool) t.join();
 }
 
@@ -153,7 +162,7 @@ int64_t dnp_xyz_format_f32(const float* rows, int64_t n_rows, int64_t n_cols, ch
     // blocks of rows on up to kIoThreads host threads: every block is formatted at the place its bound reserves in `out`
     // (disjoint by construction), then the blocks are moved down to close the gaps - byte for byte the serial text
     const int64_t blocks = io_blocks(n_rows);
-    std::vector<int64_t> len((size_t)blocks, 0);
+    int64_t len[kIoThreads] = {0};
     auto format_block = [&](int64_t b) {
         const int64_t r0 = n_rows * b / blocks, r1 = n_rows * (b + 1) / blocks;
         char* o = out + r0 * n_cols * 26;
@@ -165,13 +174,13 @@ int64_t dnp_xyz_format_f32(const float* rows, int64_t n_rows, int64_t n_cols, ch
                 n += py_repr((double)rows[r * n_cols + c], o + n);   // str(v) of the Python float = the float32 as a double
             }
         }
-        len[(size_t)b] = n;
+        len[b] = n;
     };
     run_blocks(blocks, format_block);
     int64_t n = len[0];
     for (int64_t b = 1; b < blocks; ++b) {
-        memmove(out + n, out + (n_rows * b / blocks) * n_cols * 26, (size_t)len[(size_t)b]);
-        n += len[(size_t)b];
+        memmove(out + n, out + (n_rows * b / blocks) * n_cols * 26, (size_t)len[b]);
+        n += len[b];
     }
     return n;
 }
@@ -195,6 +204,7 @@ int64_t dnp_xyz_parse_f32(const char* txt, int64_t len, float* out, int64_t max_
         if (rows >= 0) *ncol = cols;
         return rows;
     }
+    try {
     std::vector<const char*> cut((size_t)blocks + 1, txt + len);
     cut[0] = txt;
     for (int64_t b = 1; b < blocks; ++b) {
@@ -207,8 +217,12 @@ int64_t dnp_xyz_parse_f32(const char* txt, int64_t len, float* out, int64_t max_
     std::vector<int64_t> rows((size_t)blocks, 0);
     std::vector<int> cols((size_t)blocks, 0);
     run_blocks(blocks, [&](int64_t b) {
-        vals[(size_t)b].reserve((size_t)((cut[(size_t)b + 1] - cut[(size_t)b]) / 8 + 6));
-        rows[(size_t)b] = parse_lines(cut[(size_t)b], cut[(size_t)b + 1], &vals[(size_t)b], nullptr, 0, &cols[(size_t)b]);
+        try {
+            vals[(size_t)b].reserve((size_t)((cut[(size_t)b + 1] - cut[(size_t)b]) / 8 + 6));
+            rows[(size_t)b] = parse_lines(cut[(size_t)b], cut[(size_t)b + 1], &vals[(size_t)b], nullptr, 0, &cols[(size_t)b]);
+        } catch (...) {                                  // out of memory in a worker: the caller's line-by-line path decides
+            rows[(size_t)b] = -2;
+        }
     });
     int64_t total = 0;
     int c = 0;
@@ -229,6 +243,9 @@ int64_t dnp_xyz_parse_f32(const char* txt, int64_t len, float* out, int64_t max_
     }
     *ncol = c;
     return total;
+    } catch (...) {                                      // allocation failure: not a verdict on the text
+        return -2;
+    }
 }
 
 }  // extern "C"
