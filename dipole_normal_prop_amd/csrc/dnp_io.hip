@@ -79,7 +79,6 @@ template <typename Fn>
 static void run_blocks(int64_t blocks, Fn&& fn) {
     if (blocks <= 1) { fn((int64_t)0); return; }
     std::vector<std::thread> pool;
-    pool.reserve((size_t)blocks - 1);
     int64_t inline_from = blocks;                       // blocks [inline_from, blocks) run here when no thread could be started
     for (int64_t b = 1; b < blocks; ++b) {
         try {
