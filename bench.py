@@ -205,6 +205,9 @@ def main():
         p_lo, p_hi = int(fb[0]), int(fb[1])
     my_pairs = float((sizes[p_lo:p_hi] * (N_POINTS - sizes[p_lo:p_hi])).sum())
     split = fu._pick_source_split(sizes[p_lo:p_hi], N_POINTS)     # the drivers' rule: short launches split their items
+    # N > 1 over RCCL: the W-row all-gather is asynchronous (BENCH_SYNC_GATHER=1 keeps it in the launch stream's order)
+    overlap_gather = world > 1 and backend == "nccl" and not os.environ.get("BENCH_SYNC_GATHER")
+    pending = []
 
     # HIP events on the stream the kernels are launched on (torch's current stream = what _lib.current_stream() hands
     # to the C ABI), recorded INSIDE the timed steps: the pair kernel's duration, the interaction kernel's and the
@@ -228,12 +231,24 @@ def main():
             W = fu._interaction_rows(dE, pts, off, idx)
         if marks is not None and marks[2] is not None:
             marks[2].record()
-        W = parallel.gather_rows(W, bounds)
+        if overlap_gather:
+            # the all-gather of this step's W rows runs on RCCL's stream and overlaps the NEXT step's pair kernel (the
+            # steps are independent batches); two in flight at most: the gather of step i - 2 is consumed before step i
+            # issues its own.  marks[2..3] then time the enqueue only.
+            W, work = parallel.gather_rows_async(W, bounds)
+            if work is not None:
+                pending.append((W, work))
+                while len(pending) > 2:
+                    pending.pop(0)[1].wait()
+        else:
+            W = parallel.gather_rows(W, bounds)
         if marks is not None and marks[2] is not None:
             marks[3].record()
         return W
 
     def fence():
+        while pending:                         # every all-gather issued so far is complete before the barrier
+            pending.pop(0)[1].wait()
         if world > 1:
             # device_ids: under nccl a barrier without it guesses the device from the rank
             dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
@@ -310,7 +325,8 @@ def main():
     step_parts = {"pair_kernel_ms": k_ms, "interactions_kernel_ms": float(k3_all.mean()),
                   "interactions_from": "pair-kernel epilogue partials + dnp_interactions_from_tiles" if tiles.fused
                   else "dnp_interactions_f32 (second pass over the slabs)",
-                  "gather_rows_ms": float(ag_all.mean())}
+                  "gather_rows_ms": float(ag_all.mean()),
+                  "gather_rows_timed": "enqueue only: the all-gather is asynchronous" if overlap_gather else "in the launch stream's order"}
     per_rank = None
     if world > 1:
         # so that a scaling run explains itself: every rank's kernel time and its wait in the all-gather
@@ -370,7 +386,8 @@ def main():
                                       "config 4)", "points": N_POINTS,
                           "patches": N_PATCHES, "pairs_per_step": pairs_total,
                           "parallelism": f"patch-sharded x{world}, " + ("RCCL" if backend == "nccl" else backend) +
-                                         " all-gather of W rows"},
+                                         " all-gather of W rows" +
+                                         (" (asynchronous, two in flight: overlaps the next step's pair kernel)" if overlap_gather else "")},
                "roofline": roofline, "hbm": hbm, "step_parts": step_parts, "signs_ok": signs_ok,
                "trace_matches_reference_G19": trace_matches_reference, "chosen_max_rel_dev_vs_G19": chosen_dev}
         if per_rank is not None:

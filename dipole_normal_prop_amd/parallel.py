@@ -59,6 +59,23 @@ def gather_rows(W_local: torch.Tensor, bounds: np.ndarray, group=None) -> torch.
     return torch.cat([out[r, : int(rows[r])] for r in range(size)], dim=0)
 
 
+def gather_rows_async(W_local: torch.Tensor, bounds: np.ndarray, group=None, force: bool = False):
+    """gather_rows issued WITHOUT making the caller's stream wait: returns (W, work).  W is complete once work.wait() has
+    been called (a stream-side wait, the host does not block) - until then the collective runs on RCCL's own stream, behind
+    the kernels that produced W_local, and whatever the caller launches next overlaps it (a caller that evaluates batch
+    after batch: the all-gather of one batch under the pair kernel of the next).  Falls back to the synchronous form
+    (work = None) where the backend stages through the host (gloo), for unequal blocks, and for a single rank
+    (`force`: run the one-rank collective anyway - the probe of this code path on a one-GPU box)."""
+    rank, size = world()
+    rows = np.diff(bounds)
+    if ((size == 1 and not force) or not dist.is_initialized() or _host_staged(W_local) or not W_local.is_cuda
+            or int(rows.min()) != int(rows.max())):
+        return gather_rows(W_local, bounds, group), None
+    out = torch.empty((int(rows.sum()), W_local.shape[1]), dtype=W_local.dtype, device=W_local.device)
+    work = dist.all_gather_into_tensor(out, W_local.contiguous(), group=group, async_op=True)
+    return out, work
+
+
 def reduce_field(E_partial: torch.Tensor, group=None) -> torch.Tensor:
     """Sum the per-rank partial fields (each rank combined its own slabs, in fp64) on every rank.  The partial
     sums are fp64 sums of +-1-signed fp32 slabs, so the total is independent of the split over ranks up to

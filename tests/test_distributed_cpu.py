@@ -152,6 +152,8 @@ def _gather_worker(rank, world, port, sizes, q):
         bounds = fu._balanced_blocks(np.asarray(sizes), world)
         lo, hi = int(bounds[rank]), int(bounds[rank + 1])
         full = parallel.gather_rows(W[lo:hi].clone(), bounds)
+        again, work = parallel.gather_rows_async(W[lo:hi].clone(), bounds)     # host tensors over gloo: the synchronous form, no handle
+        assert work is None and torch.equal(again, full)
         E = parallel.reduce_field(torch.full((7, 3), float(rank + 1), dtype=torch.float64))
         start = parallel.agree_on_start(torch.tensor([rank + 40]))
         q.put((rank, bool(torch.equal(full, W)), float(E[0, 0]), int(start[0]), bounds.tolist()))
