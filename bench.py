@@ -208,6 +208,7 @@ def main():
     # N > 1 over RCCL: the W-row all-gather is asynchronous (BENCH_SYNC_GATHER=1 keeps it in the launch stream's order)
     overlap_gather = world > 1 and backend == "nccl" and not os.environ.get("BENCH_SYNC_GATHER")
     pending = []
+    overlap_state = {"on": overlap_gather}
 
     # HIP events on the stream the kernels are launched on (torch's current stream = what _lib.current_stream() hands
     # to the C ABI), recorded INSIDE the timed steps: the pair kernel's duration, the interaction kernel's and the
@@ -231,11 +232,16 @@ def main():
             W = fu._interaction_rows(dE, pts, off, idx)
         if marks is not None and marks[2] is not None:
             marks[2].record()
-        if overlap_gather:
+        if overlap_state["on"]:
             # the all-gather of this step's W rows runs on RCCL's stream and overlaps the NEXT step's pair kernel (the
             # steps are independent batches); two in flight at most: the gather of step i - 2 is consumed before step i
             # issues its own.  marks[2..3] then time the enqueue only.
-            W, work = parallel.gather_rows_async(W, bounds)
+            try:
+                W, work = parallel.gather_rows_async(W, bounds)
+            except Exception as exc:           # never lose a scaling run to the overlap: fall back to the in-order gather
+                print(f"bench: asynchronous all-gather unavailable ({exc!r}); continuing with the in-order form", file=sys.stderr)
+                overlap_state["on"] = False
+                W, work = parallel.gather_rows(W, bounds), None
             if work is not None:
                 pending.append((W, work))
                 while len(pending) > 2:
@@ -326,7 +332,7 @@ def main():
                   "interactions_from": "pair-kernel epilogue partials + dnp_interactions_from_tiles" if tiles.fused
                   else "dnp_interactions_f32 (second pass over the slabs)",
                   "gather_rows_ms": float(ag_all.mean()),
-                  "gather_rows_timed": "enqueue only: the all-gather is asynchronous" if overlap_gather else "in the launch stream's order"}
+                  "gather_rows_timed": "enqueue only: the all-gather is asynchronous" if overlap_state["on"] else "in the launch stream's order"}
     per_rank = None
     if world > 1:
         # so that a scaling run explains itself: every rank's kernel time and its wait in the all-gather
@@ -387,7 +393,7 @@ def main():
                           "patches": N_PATCHES, "pairs_per_step": pairs_total,
                           "parallelism": f"patch-sharded x{world}, " + ("RCCL" if backend == "nccl" else backend) +
                                          " all-gather of W rows" +
-                                         (" (asynchronous, two in flight: overlaps the next step's pair kernel)" if overlap_gather else "")},
+                                         (" (asynchronous, two in flight: overlaps the next step's pair kernel)" if overlap_state["on"] else "")},
                "roofline": roofline, "hbm": hbm, "step_parts": step_parts, "signs_ok": signs_ok,
                "trace_matches_reference_G19": trace_matches_reference, "chosen_max_rel_dev_vs_G19": chosen_dev}
         if per_rank is not None:
