@@ -562,7 +562,11 @@ __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, cons
 // nothing but the rewritten loop; profiles/r03_ab_source_split.txt).  Chunks of more than SS runs are evaluated by wavefront 0 alone
 // (the launchers do not pick SS > 1 for those).  A work item is up to SS times shorter, so the end of a launch - when
 // the last items run on a chip that is emptying - shrinks with it, for more workgroups with the same prologue; the
-// launchers use it for SHORT launches only (a rank's share of an 8-way sharded evaluation, small clouds).
+// launchers use it for SHORT launches only (a rank's share of an 8-way sharded evaluation, small clouds), and there only
+// for the LAST chunks of the launch:
+// TAIL (with SS = 4, WAVES = 4): one launch, a 1-D grid - first the chunks [0, split_from) in the SS = 1 way (the workgroup's
+// four wavefronts on four target tiles), then the chunks from split_from on in the SS = 4 way; workgroups start in grid
+// order, so the launch's last resident set is made of short items.  The same bits again (both forms are).
 // WAVES: wavefronts per workgroup (launch with WAVES * 64 threads).  The wavefronts of this kernel do not cooperate
 // (SS = 1, boxes from tables), so the workgroup is only the unit of dispatch: with the XCD-aware tile mapping below, 2
 // wavefronts measured 4.049 ms on the bench launch against 4.074 with 4 (a CU takes a new pair of wavefronts as soon as
