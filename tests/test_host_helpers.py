@@ -243,3 +243,22 @@ def test_fused_interaction_rule_and_source_split_policy():
     assert fu._pick_source_split(big[:48], 100000) == 1                   # 1.87e9 pairs: above the threshold
     assert fu._pick_source_split(np.array([128, 300]), 1000) == 1 and fu._pick_source_split(np.array([129, 512]), 1000) == -3
     assert fu._pick_source_split(np.array([], dtype=np.int64), 1000) == 1
+
+
+def test_store_normals_writes_any_host_tensor_through_one_copy():
+    """field_utils._store_normals (the write-back of the drivers for HOST tensors): fp32 / fp64 tensors, a strided view of a
+    wider tensor, a dtype numpy cannot view (fp16: the torch path), xyz columns and neighbouring columns untouched."""
+    from dipole_normal_prop_amd import field_utils as fu
+    n = torch.randn(500, 3)
+    for dt in (torch.float32, torch.float64, torch.float16):
+        pts = torch.randn(500, 6).to(dt)
+        xyz = pts[:, :3].clone()
+        fu._store_normals(pts, n)
+        assert torch.equal(pts[:, 3:], n.to(dt)) and torch.equal(pts[:, :3], xyz)
+    wide = torch.zeros(500, 9, dtype=torch.float64)
+    fu._store_normals(wide[:, 2:8], n)
+    assert torch.equal(wide[:, 5:8], n.double()) and float(wide[:, :5].abs().max()) == 0 and float(wide[:, 8].abs().max()) == 0
+    grad = torch.randn(10, 6, requires_grad=True)
+    with torch.no_grad():
+        fu._store_normals(grad, torch.ones(10, 3))               # a leaf that requires grad: the torch path, under no_grad
+    assert bool((grad[:, 3:] == 1).all())
