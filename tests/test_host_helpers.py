@@ -262,3 +262,13 @@ def test_store_normals_writes_any_host_tensor_through_one_copy():
     with torch.no_grad():
         fu._store_normals(grad, torch.ones(10, 3))               # a leaf that requires grad: the torch path, under no_grad
     assert bool((grad[:, 3:] == 1).all())
+
+
+def test_native_xyz_parser_row_bound_is_tight_for_minimal_rows():
+    """util._xyz_native sizes its output from the text length (a row is at least "1 2 3" + newline): shortest possible rows,
+    with and without the final newline, long enough for the threaded path."""
+    for n in (1, 2, 7, 30000):
+        for tail in ("", "\n"):
+            txt = "\n".join(["1 2 3"] * n) + tail
+            got = util._xyz_native(txt, False)
+            assert got is not None and got.shape == (n, 3) and float((got - torch.tensor([1.0, 2.0, 3.0])).abs().max()) == 0
