@@ -852,6 +852,15 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
         }
     }
 
+#ifdef DNP_DUMMY_LDS   // experiment builds only (profiles/r03_tail_fill.txt): what does it cost a kernel whose wavefronts share nothing to
+                       // CARRY an LDS allocation and a barrier (1: never executed - a.T < 0 is false; 2: executed by every workgroup)
+    if (DNP_DUMMY_LDS == 2 || a.T < 0) {
+        __shared__ double dummy_lds[1152];
+        dummy_lds[tid] = acc[0][0];
+        __syncthreads();
+        if (dummy_lds[(tid + 1) % (WAVES * 64)] == 1.2345e300) acc[0][0] += 1.0;
+    }
+#endif
     const int64_t chunk_id = a.chunk_base + chunk;
     double w_first = 0.0, w_other = 0.0;                  // WPART: this lane's share of the tile's interaction sums
     int64_t g_first = 0;
