@@ -855,10 +855,13 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
 #ifdef DNP_DUMMY_LDS   // experiment builds only (profiles/r03_tail_fill.txt): what does it cost a kernel whose wavefronts share nothing to
                        // CARRY an LDS allocation and a barrier (1: never executed - a.T < 0 is false; 2: executed by every workgroup)
     if (DNP_DUMMY_LDS == 2 || a.T < 0) {
-        __shared__ double dummy_lds[1152];
-        dummy_lds[tid] = acc[0][0];
+#ifndef DNP_DUMMY_LDS_DOUBLES
+#define DNP_DUMMY_LDS_DOUBLES 1152
+#endif
+        __shared__ double dummy_lds[DNP_DUMMY_LDS_DOUBLES];
+        dummy_lds[tid % DNP_DUMMY_LDS_DOUBLES] = acc[0][0];
         __syncthreads();
-        if (dummy_lds[(tid + 1) % (WAVES * 64)] == 1.2345e300) acc[0][0] += 1.0;
+        if (dummy_lds[(tid + 1) % (DNP_DUMMY_LDS_DOUBLES < WAVES * 64 ? DNP_DUMMY_LDS_DOUBLES : WAVES * 64)] == 1.2345e300) acc[0][0] += 1.0;
     }
 #endif
     const int64_t chunk_id = a.chunk_base + chunk;
