@@ -23,6 +23,10 @@ constexpr bool kPatchFar = DNP_FAR != 0;
 #define DNP_TABLED_WAVES 2
 #endif
 constexpr int kTabledWaves = DNP_TABLED_WAVES;
+#ifndef DNP_XCH_WAVES        // wavefronts per workgroup of the launches with a split tail (A/B builds: 1, 2, 4)
+#define DNP_XCH_WAVES 4
+#endif
+constexpr int kXchWaves = DNP_XCH_WAVES;
 #ifndef DNP_FORCE_LDS   // A/B builds only (tools/gpu_ab_far.py): 1 sends the sorted layout through the LDS kernel too
 #define DNP_FORCE_LDS 0
 #endif
@@ -196,16 +200,32 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts, cons
                                const float* patch_box, int64_t p_begin, int64_t p_end, float eps, float* dE,
                                void* stream) {
     return dnp_patch_fields_tiled_f32(pts, N, ld_pts, patch_off, patch_idx, P, point_patch, patch_box, nullptr, p_begin,
-                                      p_end, eps, dE, nullptr, 1, stream);
+                                      p_end, eps, dE, nullptr, 1, nullptr, 0, stream);
+}
+
+// exchange buffer of the split forms: one record per (split patch, target tile) - the arrival counter in a 128-byte line of
+// its own, then 4 runs x 6 doubles x 64 lanes of run terms (pair_kernel.h, xch_item_bytes)
+size_t dnp_patch_exchange_bytes(int64_t N, int64_t split_patches) {
+    if (N <= 0 || split_patches <= 0) return 0;
+    return (size_t)split_patches * (size_t)ceil_div(N, (int64_t)64 * kPatchScalarKT) * (size_t)xch_item_bytes(4, kPatchScalarKT, 3);
+}
+
+int dnp_exchange_init(void* exchange, size_t bytes, void* stream) {
+    clear_error();
+    if (bytes == 0) return DNP_OK;
+    DNP_REQUIRE(exchange, "NULL exchange buffer");
+    DNP_CHECK_HIP(hipMemsetAsync(exchange, 0, bytes, (hipStream_t)stream));
+    return DNP_OK;
 }
 
 int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
                                const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
                                const float* patch_box, const float* tile_box, int64_t p_begin, int64_t p_end, float eps,
-                               float* dE, double* w_part, int source_split, void* stream) {
+                               float* dE, double* w_part, int source_split, void* exchange, size_t exchange_bytes,
+                               void* stream) {
     clear_error();
-    DNP_REQUIRE(source_split == 1 || source_split == 4 || (source_split < 0 && source_split >= -65535),
-                "source_split=%d (1, 4, or -k: the last k patches split)", source_split);
+    DNP_REQUIRE(source_split == 1 || (source_split < 0 && source_split >= -65535),
+                "source_split=%d (1, or -k: the last k patches of the launch as split items)", source_split);
     DNP_REQUIRE(N >= 0 && P >= 0, "negative size");
     DNP_REQUIRE(0 <= p_begin && p_begin <= p_end && p_end <= P, "bad patch range [%lld,%lld) of %lld",
                 (long long)p_begin, (long long)p_end, (long long)P);
@@ -234,47 +254,54 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
         if (scalar_path) {
             // patch-sorted cloud (what the drivers pass): contiguous sources -> the scalar-unit kernel
             const bool tabled = patch_box && tile_box && kPatchFar && pa.far_d2 > 0.f;
-            // the source split exists for the fully tabled form only; -k (the last k patches of the launch split, ONE launch:
-            // pair_kernel.h TAIL) needs the whole range in this slice and at least one unsplit patch
-            const int tail = (tabled && source_split < 0 && k0 == 0 && kn == K && -source_split < K) ? -source_split : 0;
-            int ss = 1;
-            if (tabled && source_split > 0) ss = source_split;
-            else if (tabled && !tail && -source_split >= K) ss = 4;     // -k with k >= the whole range: every patch split
-            // the tabled, unsplit form runs in workgroups of kTabledWaves wavefronts (pair_kernel.h, WAVES)
-            const int waves = (tabled && ss == 1) ? kTabledWaves : kBlock / 64;
-            const dim3 sgrid((unsigned)ceil_div(N, (int64_t)(waves / ss) * 64 * kPatchScalarKT), (unsigned)kn);
+            // -k: ONE launch whose last k patches are split items with their run terms in the exchange buffer
+            // (pair_kernel.h XCH); it exists for the fully tabled form, needs the whole range in this slice, and k >= the
+            // range means every patch
+            const int tail = (tabled && source_split < 0 && k0 == 0 && kn == K) ? (int)(-source_split < K ? -source_split : K) : 0;
             pa.chunk_box = patch_box;
             pa.tile_box = tile_box;
             pa.w_part = w_part ? w_part + k0 * ceil_div(N, (int64_t)64 * kPatchScalarKT) * 2 : nullptr;
-#define DNP_LAUNCH_TABLED(WP, SS, WV)                                                                                    \
-    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, WP, SS, WV>), \
-                       sgrid, dim3(WV * 64), 0, st, pa)
             if (tail) {
                 const int64_t n_tiles = ceil_div(N, (int64_t)64 * kPatchScalarKT);
-                const int64_t blocks = (K - tail) * ceil_div(n_tiles, (int64_t)4) + (int64_t)tail * n_tiles;
+                const size_t need = dnp_patch_exchange_bytes(N, tail);
+                if (!exchange || exchange_bytes < need) {
+                    set_error("exchange buffer of %zu bytes required for %d split patches, %zu given", need, tail,
+                              exchange ? exchange_bytes : (size_t)0);
+                    return DNP_EWORKSPACE;
+                }
+                constexpr int kW = kXchWaves;
+                // split part: per patch the tiles padded to a multiple of 8 (XCD-first numbering), 4 / kW workgroups per tile
+                const int64_t blocks = (K - tail) * ceil_div(n_tiles, (int64_t)kW) + (int64_t)tail * ceil_div(n_tiles, (int64_t)8) * 8 * (4 / kW);
                 DNP_REQUIRE(blocks < ((int64_t)1 << 31), "the tail form's grid of %lld workgroups", (long long)blocks);
                 pa.split_from = (int)(K - tail);
+                pa.n_chunks = (int)K;
+                pa.xch_ticket = (unsigned int*)exchange;
+                pa.xch_terms = (double*)((char*)exchange + 128);
                 const dim3 tgrid((unsigned)blocks);
                 if (w_part)
-                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, true, 4, 4, true>),
-                                       tgrid, dim3(256), 0, st, pa);
+                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, true, 4, kW, true>),
+                                       tgrid, dim3(kW * 64), 0, st, pa);
                 else
-                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, false, 4, 4, true>),
-                                       tgrid, dim3(256), 0, st, pa);
-            } else if (tabled && w_part) {
-                if (ss == 4) DNP_LAUNCH_TABLED(true, 4, 4);
-                else DNP_LAUNCH_TABLED(true, 1, kTabledWaves);
+                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, false, 4, kW, true>),
+                                       tgrid, dim3(kW * 64), 0, st, pa);
             } else if (tabled) {
-                if (ss == 4) DNP_LAUNCH_TABLED(false, 4, 4);
-                else DNP_LAUNCH_TABLED(false, 1, kTabledWaves);
+                // the tabled, unsplit form runs in workgroups of kTabledWaves wavefronts (pair_kernel.h, WAVES)
+                const dim3 sgrid((unsigned)ceil_div(N, (int64_t)kTabledWaves * 64 * kPatchScalarKT), (unsigned)kn);
+                if (w_part)
+                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, true, 1, kTabledWaves>),
+                                       sgrid, dim3(kTabledWaves * 64), 0, st, pa);
+                else
+                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, false, 1, kTabledWaves>),
+                                       sgrid, dim3(kTabledWaves * 64), 0, st, pa);
+            } else {
+                const dim3 sgrid((unsigned)ceil_div(N, (int64_t)(kBlock / 64) * 64 * kPatchScalarKT), (unsigned)kn);
+                if (patch_box && kPatchFar)
+                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true>), sgrid,
+                                       dim3(kBlock), 0, st, pa);
+                else
+                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar>), sgrid,
+                                       dim3(kBlock), 0, st, pa);
             }
-#undef DNP_LAUNCH_TABLED
-            else if (patch_box && kPatchFar)
-                hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true>), sgrid,
-                                   dim3(kBlock), 0, st, pa);
-            else
-                hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar>), sgrid,
-                                   dim3(kBlock), 0, st, pa);
         } else {
             const dim3 grid((unsigned)t_tiles, (unsigned)kn);
             if (eps > 0.f)

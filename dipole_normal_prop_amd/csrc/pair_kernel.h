@@ -120,6 +120,8 @@ constexpr int kSets = DNP_SETS;   // interleaved fp32 accumulator sets (chain le
 #endif
 constexpr int kUnroll = DNP_UNROLL;  // sources per inner-loop iteration (multiple of kSets; source u -> set u % kSets)
 constexpr int kMaxChunks = 512;   // by-value chunk table entries per launch (2 KB of kernarg)
+// bytes of one record of the exchange buffer (PairArgs::xch_ticket): a 128-byte line for the arrival counter + the run terms
+constexpr int64_t xch_item_bytes(int ss, int kt, int nc) { return 128 + (int64_t)ss * kt * nc * 64 * (int64_t)sizeof(double); }
 
 enum PairMode { kField = 0, kPotential = 1 };
 
@@ -147,7 +149,13 @@ struct PairArgs {
     F far_d2;                // scalar kernel, FAR: squared box distance beyond which the one-transcendental chain runs
     const F* tile_box;       // scalar kernel, TBOX: [ceil(T / (64 KT))][6] boxes of the wavefronts' target tiles (dnp_tile_boxes_f32)
     double* w_part;          // scalar kernel, WPART: [gridDim.y][ceil(T / (64 KT))][2] per-(slab, tile) interaction partials
-    int split_from;          // scalar kernel, TAIL: chunks [split_from, n) of the launch are evaluated with the source split
+    int split_from;          // scalar kernel, XCH: chunks [split_from, n) of the launch are evaluated with the source split
+    int n_chunks;            // scalar kernel, XCH: chunks of the launch (its grid is 1-D)
+    // XCH: the exchange buffer, one record per (split chunk, target tile) item: [arrival counter, padded to a 128-byte line]
+    // [SS][KT * NC][64] run terms (fp64).  A record's place depends on the item's index only, so launches of any size keep
+    // their counters in the same words: zero before the first launch, left zero by every launch.
+    unsigned int* xch_ticket;  // = the buffer; item i's counter is xch_ticket[i * xch_item_bytes / 4]
+    double* xch_terms;         // = the buffer + 128 bytes; item i's terms start at xch_terms[i * xch_item_bytes / 8]
     int32_t chunk_off[kMaxChunks + 1];  // by-value CSR offsets when chunk_off_dev == nullptr
 };
 
@@ -554,41 +562,57 @@ __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, cons
 // epilogue also leaves sum_t dE[t] . n_t of the tile's targets, split by group (the tile's first group / the other one),
 // in a.w_part - the patch interaction matrix W then needs no second pass over the slabs (dnp_interactions_from_tiles).
 //
-// SS (1, 2, 4): SOURCE SPLIT inside the workgroup.  With SS = 1 the four wavefronts own four target tiles and each runs
-// the whole chunk; with SS = 4 (2) they own one tile (two) and wavefront i runs the chunk's i-th RUN (see "the chunk's
-// runs" in the kernel), the run terms meet in LDS (fp64) and wavefront 0 adds them IN RUN ORDER and finishes - the same
-// fp32 runs and the same fp64 additions as SS = 1 performs, so the results do not depend on SS, and the SS = 1 loop
-// keeps its form (a first version that rewrote the run loop around quarter cuts cost the SS = 1 path 1 % through
-// nothing but the rewritten loop; profiles/r03_ab_source_split.txt).  Chunks of more than SS runs are evaluated by wavefront 0 alone
-// (the launchers do not pick SS > 1 for those).  A work item is up to SS times shorter, so the end of a launch - when
-// the last items run on a chip that is emptying - shrinks with it, for more workgroups with the same prologue; the
-// launchers use it for SHORT launches only (a rank's share of an 8-way sharded evaluation, small clouds), and there only
-// for the LAST chunks of the launch:
-// TAIL (with SS = 4, WAVES = 4): one launch, a 1-D grid - first the chunks [0, split_from) in the SS = 1 way (the workgroup's
-// four wavefronts on four target tiles), then the chunks from split_from on in the SS = 4 way; workgroups start in grid
-// order, so the launch's last resident set is made of short items.  The same bits again (both forms are).
-// WAVES: wavefronts per workgroup (launch with WAVES * 64 threads).  The wavefronts of this kernel do not cooperate
-// (SS = 1, boxes from tables), so the workgroup is only the unit of dispatch: with the XCD-aware tile mapping below, 2
-// wavefronts measured 4.049 ms on the bench launch against 4.074 with 4 (a CU takes a new pair of wavefronts as soon as
-// two slots are free) and 4.060 with 1 (profiles/r03_ab_block.txt).  SS > 1 needs WAVES = 4.
+// SS (1, 2, 4): SOURCE SPLIT.  With SS = 1 the wavefronts of a workgroup own one target tile each and run the whole
+// chunk; with SS > 1 a tile's chunk is evaluated by SS wavefronts and the partial sums are added IN A FIXED ORDER - the
+// same fp32 runs and the same fp64 additions whatever SS, so results do not depend on it, and the SS = 1 loop keeps its
+// form (a first version that rewrote the run loop around quarter cuts cost the SS = 1 path 1 % through nothing but the
+// rewritten loop; profiles/r03_ab_source_split.txt).  A work item is up to SS times shorter, so the end of a launch - the
+// last items on a chip that is emptying - shrinks with it, for more wavefronts with the same prologue.  Two forms:
+//   * fp64 partial slabs (the generic entry points, far-field launches): the chunk is cut into SS equal PARTS, the four
+//     wavefronts of a workgroup take one each with their own far-field decision, the part sums meet in LDS and wavefront 0
+//     adds them in part order ("kParts" below).
+//   * XCH (round 4; fp32 slabs, the patch drivers' tabled form): the split WITHOUT LDS, for the LAST chunks of a launch.
+//     Wavefront i of a split item runs the chunk's i-th RUN of 128 sources (chunks of more than SS runs are left to
+//     wavefront 0), writes its run term to the exchange buffer with write-through (sc1) stores, waits for them
+//     (vmcnt(0)) and draws a ticket from the item's arrival counter with one agent-scope atomic add; the wavefront that
+//     draws the last ticket acquires, reads the SS terms back, adds them in run order and runs the epilogue; the others
+//     are done.  No LDS, no barrier, nobody waits, correct for any placement of the wavefronts over CUs and XCDs
+//     (MI355X_MICROARCH.md, price list rows dequeue / splitk-seam: sc1 slab stores + a ticket + the last arriver).  The
+//     launch is a 1-D grid: first the chunks [0, split_from) unsplit - WAVES wavefronts per workgroup on WAVES target
+//     tiles -, then the split chunks, one (tile, run) item per wavefront; workgroups start in grid order, so the launch's
+//     last resident set consists of items a third as long and the chip drains in a third of the time
+//     (profiles/r03_timeline.txt: 49 us of a 0.56 ms launch were drain).  Round 3 built this tail with the run terms in
+//     LDS: a kernel whose wavefronts share nothing pays 2.4 % for merely CARRYING 9 KB of LDS and a barrier
+//     (profiles/r03_tail_fill.txt), so that tail lost above 44 patches per launch; this one pays at every size
+//     (profiles/r04_xch_ab.txt: -11 % at 16 patches, -3.7 % at 32 - a rank's share of eight -, -0.5 % at 128) and the hand-off
+//     itself - stores, wait, ticket, acquire, 24 loads - is 3 % of a split item.
+// WAVES: wavefronts per workgroup (launch with WAVES * 64 threads).  The wavefronts of the tabled kernel do not cooperate
+// (SS = 1 or XCH, boxes from tables), so the workgroup is only the unit of dispatch: with the XCD-aware tile mapping
+// below, 2 wavefronts measured 4.049 ms on the bench launch against 4.074 with 4 (a CU takes a new pair of wavefronts as
+// soon as two slots are free) and 4.060 with 1 (profiles/r03_ab_block.txt).  The XCH launches use 4: a tile's four runs
+// then start together on one CU, and split items in workgroups of 1 or 2 wavefronts cost +25 % instead of +4 %
+// (profiles/r04_xch_ab.txt).
 template <typename F, typename PT, int MODE, int KT, int V, bool FAR = false, bool BOX = false, bool TBOX = false,
-          bool WPART = false, int SS = 1, int WAVES = kBlock / 64, bool TAIL = false>
+          bool WPART = false, int SS = 1, int WAVES = kBlock / 64, bool XCH = false>
 __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<F, PT> a) {
     using M = Math<F>;
     constexpr int NC = (MODE == kField) ? 3 : 1;
     constexpr bool kFarPath = FAR && MODE == kField && V == kFast;
     static_assert(SS == 1 || SS == 2 || SS == 4, "source split: 1, 2 or 4 wavefronts per target tile");
     static_assert(SS == 1 || MODE == kField, "the source split is built for the field mode");
-    static_assert(WAVES % SS == 0 && WAVES >= SS, "a workgroup holds whole target tiles");
-    constexpr int kTG = WAVES / SS;                         // target tiles per workgroup
-    static_assert(!TAIL || (SS == 4 && WAVES == 4 && BOX && TBOX && sizeof(PT) == 4), "TAIL: the tabled patch-mode split kernel");
+    static_assert(XCH || (WAVES % SS == 0 && WAVES >= SS), "a workgroup holds whole target tiles");
+    constexpr int kTG = XCH ? WAVES : WAVES / SS;           // target tiles per workgroup (XCH: of an unsplit workgroup)
+    static_assert(!XCH || (SS > 1 && BOX && TBOX && sizeof(PT) == 4), "XCH: the tabled patch-mode kernel (no LDS, no barrier)");
+    static_assert(XCH || SS == 1 || sizeof(PT) == 8, "fp32 slabs split their items through the exchange buffer (XCH)");
     DNP_STAMP_BEGIN_SCALAR();
     __shared__ F chunk_box[WAVES][6];
-    __shared__ double split_terms[SS > 1 ? SS - 1 : 1][SS > 1 ? kTG : 1][KT][SS > 1 ? NC : 1][SS > 1 ? 64 : 1];
+    constexpr bool kLdsSplit = SS > 1 && !XCH;              // the split forms whose run terms meet in LDS
+    __shared__ double split_terms[kLdsSplit ? SS - 1 : 1][kLdsSplit ? kTG : 1][kLdsSplit ? KT : 1][kLdsSplit ? NC : 1][kLdsSplit ? 64 : 1];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // an SGPR: everything derived from it stays wave-uniform,
-    int tg = wave / SS, sp = wave % SS;                     // above all the source range (scalar loads); tile / source part
+    int tg = XCH ? wave : wave / SS, sp = XCH ? 0 : wave % SS;   // above all the source range (scalar loads); tile / source part
     int64_t chunk = blockIdx.y;
+    int64_t xch_item = 0;                                   // XCH: (split chunk, target tile) index of this wavefront's item
     // XCD-aware tile mapping.  Workgroups are dealt round-robin over the 8 XCDs in launch order (x fastest: XCD = linear
     // id mod 8 - observed behaviour, MI355X_MICROARCH.md; only speed depends on it).  With a grid width that is not a
     // multiple of 8 a target tile would wander over the XCDs from one chunk row to the next, and every XCD's L2 would
@@ -599,32 +623,41 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
 #define DNP_XCD_MAP 1
 #endif
     unsigned bx = blockIdx.x;
-    // TAIL: ONE launch whose last chunks are split - a 1-D grid, first the chunks [0, split_from) with a workgroup's four
-    // wavefronts on four target tiles (the SS = 1 form: every wavefront runs the whole chunk), then the chunks from
-    // split_from on with the four wavefronts on ONE tile (the SS = 4 form).  Workgroups start in grid order, so the
-    // launch's last resident set consists of items a third as long and the chip drains in a third of the time
-    // (profiles/r03_timeline.txt: 49 us of a 0.56 ms launch were drain); the bits are those of either form.
     bool row_split = SS > 1;
     int ktg = kTG;                                           // target tiles of this workgroup
-    if constexpr (TAIL) {
+    if constexpr (XCH) {
         const unsigned n_tiles = (unsigned)((a.T + 64 * KT - 1) / (64 * KT));
         const unsigned gxa = (n_tiles + WAVES - 1) / WAVES;
         const unsigned unsplit_blocks = (unsigned)a.split_from * gxa;
         const unsigned b = blockIdx.x;
-        if (b < unsplit_blocks) {
+        if (b < unsplit_blocks) {                               // the product's unsplit form: WAVES tiles per workgroup
             const unsigned row = b / gxa;
             bx = b - row * gxa;
             if (DNP_XCD_MAP && bx < (gxa & ~7u)) bx = (bx & ~7u) | ((bx + row * gxa) & 7u);
             chunk = row;
             row_split = false;
-            ktg = WAVES;
-            tg = wave;
-            sp = 0;
-        } else {
+        } else {                                                // one (tile, run) item per wavefront
+            // Workgroups go to the XCDs round-robin by their linear id, and a tile's runs are NOT equal work (a 390-point
+            // patch is 128 + 128 + 128 + 6 sources): with the workgroups of a tile on consecutive ids every XCD saw one kind
+            // of run only - even XCDs runs 0-1, odd XCDs runs 2-3 - and the split patches took 1.3 times as long as they
+            // should (profiles/r04_xch_ab.txt: all patches split +24 % with two-wavefront workgroups, +5 % with four).  So
+            // inside a patch the ids are dealt XCD-first: id = (8 j + x), tile = 8 (j / h) + x, runs WAVES (j % h) ..., with
+            // h = SS / WAVES workgroups per tile - a tile's workgroups share an XCD and every XCD gets every kind of run.
+            static_assert(SS % WAVES == 0, "XCH: whole workgroups per tile");
+            constexpr unsigned kH = SS / WAVES;
+            const unsigned n_t8 = (n_tiles + 7u) & ~7u;         // tiles padded to whole groups of 8 (the surplus ones exit)
             const unsigned c = b - unsplit_blocks;
-            const unsigned row = c / n_tiles;
-            bx = c - row * n_tiles;
+            const unsigned row = c / (n_t8 * kH);
+            const unsigned r = c - row * (n_t8 * kH);
+            const unsigned j = r >> 3;
+            const unsigned tile = (j / kH) * 8u + (r & 7u);
+            if (tile >= n_tiles) return;
+            sp = (int)((j % kH) * WAVES) + wave;
+            bx = tile;
             chunk = (int64_t)a.split_from + row;
+            ktg = 1;
+            tg = 0;
+            xch_item = (int64_t)row * n_tiles + tile;
         }
     } else {
         if (DNP_XCD_MAP && bx < (gridDim.x & ~7u)) bx = (bx & ~7u) | ((bx + blockIdx.y * gridDim.x) & 7u);
@@ -832,7 +865,48 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
                                           : (double)(P[0][k] + P[1][k]);
         }
     }
-    if (SS > 1 && row_split) {
+    if constexpr (XCH) {
+        if (row_split) {
+            if (!exchange) {
+                if (sp != 0) return;                                // a long chunk: part 0 has run all of it
+            } else {
+                // publish this run's term: write-through stores (512 contiguous bytes per instruction), then the ticket
+                constexpr int64_t kItemDoubles = xch_item_bytes(SS, KT, NC) / 8, kItemWords = xch_item_bytes(SS, KT, NC) / 4;
+                unsigned int* ticket = a.xch_ticket + xch_item * kItemWords;
+                double* slot = a.xch_terms + xch_item * kItemDoubles + (sp * (KT * NC)) * 64 + (tid & 63);
+#pragma unroll
+                for (int k = 0; k < KT; ++k)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        __hip_atomic_store(slot + (k * NC + c) * 64, acc[k][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wavefront's stores have left before it signals
+                unsigned drawn = 0;
+                if ((tid & 63) == 0)
+                    drawn = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                drawn = (unsigned)__builtin_amdgcn_readfirstlane((int)drawn);
+                if (drawn != SS - 1) return;                        // somebody else arrives last and finishes the item
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if ((tid & 63) == 0)                                // re-armed for the next launch on this buffer
+                    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double* terms = a.xch_terms + xch_item * kItemDoubles + (tid & 63);
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    // one target's SS * NC loads in flight at a time: all KT * SS * NC at once (what hipcc schedules by itself)
+                    // cost 66 VGPRs, i.e. one wavefront per SIMD for the WHOLE kernel
+                    if (k > 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {                   // run order: ((t0 + t1) + t2) + t3, the unsplit form's additions
+                        double sum = __hip_atomic_load(terms + (k * NC + c) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int q = 1; q < SS; ++q)
+                            sum += __hip_atomic_load(terms + ((q * KT + k) * NC + c) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        acc[k][c] = sum;
+                    }
+                }
+            }
+        }
+    } else if (SS > 1 && row_split) {
         // run i's term travels on its own and part 0 adds the terms in run order: exactly the sums of the SS = 1 form
         if (exchange && sp != 0) {
 #pragma unroll

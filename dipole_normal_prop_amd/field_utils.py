@@ -566,19 +566,38 @@ def _patch_boxes(work: torch.Tensor, off, idx) -> torch.Tensor:
     return boxes
 
 
+def _exchange(nbytes: int, dev: torch.device) -> torch.Tensor:
+    """Exchange buffer of the split forms (include/dnp.h, dnp_patch_fields_tiled_f32): zero at its first use, left zero
+    by every launch that uses it; cached per (thread, device, stream) like the workspace, because one buffer serves one
+    stream at a time."""
+    cache = getattr(_tls, "xch", None)
+    if cache is None:
+        cache = _tls.xch = {}
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = cache[key] = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+    return buf
+
+
 def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, eps: float, boxes=None, tile_boxes=None,
                  w_part: Optional[torch.Tensor] = None, source_split: int = 1) -> torch.Tensor:
     """dE[p1 - p0, N, 3]: the fields of patches p0..p1 on every point (dnp_patch_fields_tiled_f32).  boxes / tile_boxes:
     the per-cloud box tables of the far-field test (_patch_boxes, _tile_boxes); w_part: receives the per-tile
-    interaction partials (see _TileTables)."""
+    interaction partials (see _TileTables).  source_split = -k: the last k patches of the launch as split items whose run
+    terms travel through the exchange buffer (needs both box tables; without them the launch is the plain one)."""
     lib = _lib.require_device()
     N = work.shape[0]
     dE = torch.empty((p1 - p0, N, 3), dtype=torch.float32, device=work.device)
+    xch, xch_bytes = None, 0
+    if source_split < 0 and boxes is not None and tile_boxes is not None:
+        xch_bytes = int(lib.dnp_patch_exchange_bytes(N, min(-source_split, p1 - p0)))
+        xch = _exchange(xch_bytes, work.device)
     with _on_device(work.device):
         rc = lib.dnp_patch_fields_tiled_f32(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
                                             off.shape[0] - 1, _lib.ptr(point_patch), _lib.ptr(boxes), _lib.ptr(tile_boxes),
                                             p0, p1, float(eps), _lib.ptr(dE), _lib.ptr(w_part), int(source_split),
-                                            _lib.current_stream())
+                                            _lib.ptr(xch), xch_bytes, _lib.current_stream())
     _lib.check(rc)
     return dE
 
@@ -616,22 +635,23 @@ class _TileTables:
         self.fused = _tiles_within_two_groups(sizes, N, self.rows)
 
 
-# Source split of the pair kernel's work items (include/dnp.h, dnp_patch_fields_tiled_f32).  A launch ends with ~50 us of a
-# chip that is emptying, and that tail scales with the item length (profiles/r03_timeline.txt); with the four wavefronts
-# of a workgroup on ONE target tile, one 128-source run of the patch each, an item is a third as long - at the price of
-# more prologues and an almost idle fourth wavefront (a 390-point patch is 128 + 128 + 128 + 6).  So only the LAST
-# patches of a launch are split (source_split = -k: one launch, its last resident set made of short items), and only
-# for launches short enough for the tail to matter: 100 000-point sphere, ms per launch unsplit / all split / last 3 split
-# (tools/gpu_tail_fill.py, profiles/r03_tail_fill.txt): 4 patches 0.116 / 0.099 / 0.092, 16 patches 0.309 / 0.299 / 0.287,
-# 32 patches (a rank's share of 8) 0.560 / 0.578 / 0.552, 48 patches 0.808 / 0.853 / 0.812.  Results do not depend on
-# the choice (bit-identical slabs and partials).
-TAIL_BELOW_PAIRS = 1.7e9
+# Split tail of the pair kernel's launches (include/dnp.h, dnp_patch_fields_tiled_f32).  A launch ends with ~50 us of a
+# chip that is emptying, and that tail scales with the item length (profiles/r03_timeline.txt); as a split item - four
+# wavefronts on ONE target tile, one 128-source run of the patch each, the run terms added in run order by whichever
+# arrives last (exchange buffer, no LDS) - a (tile, patch) evaluation is a third as long.  So the LAST patches of a launch
+# are split (source_split = -k: one launch, its last resident set made of short items).  100 000-point sphere, the first K
+# of the 256 patches, ms per launch plain / last 3 split (tools/gpu_xch_ab.py, profiles/r04_xch_ab.txt): K = 4 0.119 / 0.097,
+# 16 0.319 / 0.281, 32 (a rank's share of 8) 0.559 / 0.538, 64 1.053 / 1.042, 128 2.047 / 2.040, 256 4.045 / 4.038 - it
+# pays at every size, by less and less; above TAIL_BELOW_PAIRS the launch stays the plain one (the gain is inside the
+# box-to-box noise there and the bench's kernel keeps its name).  Round 3's form of the tail (run terms in LDS) was worth
+# -1 % at 32 patches and cost +3 % at 256.  Results do not depend on the choice (bit-identical slabs and partials).
+TAIL_BELOW_PAIRS = 8e9
 TAIL_PATCHES = 3
 
 
 def _pick_source_split(sizes_block: np.ndarray, n_targets: int) -> int:
     """source_split for a launch over patches of these sizes: 1, or -TAIL_PATCHES (the last patches split) when the
-    launch is short and every patch has 2..4 runs of 128 sources (129..512 points)."""
+    launch is below TAIL_BELOW_PAIRS and every patch has 2..4 runs of 128 sources (129..512 points)."""
     if len(sizes_block) == 0 or int(sizes_block.min()) <= 128 or int(sizes_block.max()) > 512:
         return 1
     return -TAIL_PATCHES if float(sizes_block.sum()) * float(n_targets) < TAIL_BELOW_PAIRS else 1

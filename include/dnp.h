@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DNP_VERSION 300 /* 0.3.0 */
+#define DNP_VERSION 400 /* 0.4.0 */
 
 enum {
     DNP_OK = 0,
@@ -166,15 +166,22 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts,
  *     fixed order).  With every tile inside at most two groups (patches of >= R points; rows in no patch last) W follows
  *     from dnp_interactions_from_tiles without a second pass over the 12 N P bytes of slabs; the caller checks that
  *     condition (the drivers do, on the host, from the patch sizes) and uses dnp_interactions_f32 otherwise.
- * source_split (1, 4 or -k; used with both tables only): with 4 the four wavefronts of a workgroup share ONE target tile
- * and wavefront i evaluates the patch's i-th run of 128 sources (the run terms meet in LDS and are added in run order):
- * work items up to four times shorter.  -k (k >= 1): ONE launch in which only the LAST k patches of the range are split
- * that way (k >= the range: all of them) - the launch's last resident set then consists of short items and the chip
- * drains in a third of the time, while the other patches keep the unsplit form's efficiency; this is what the drivers
- * use, with k = 3, for launches below 1.7 10^9 pairs (profiles/r03_tail_fill.txt, r03_timeline.txt).  dE and w_part do
- * not depend on source_split (the same fp32 runs, the same fp64 additions); patches of more than 512 points are
- * evaluated by one wavefront per tile whatever source_split says, patches of <= 128 points are a single run - so a
- * split pays only when the patches have 129..512 points (the drivers check that).
+ * source_split (1 or -k; -k needs both tables and the exchange buffer): -k (k >= 1) is ONE launch in which the LAST k patches
+ * of the range (k >= the range: all of them) are evaluated as SPLIT ITEMS - four wavefronts per target tile, wavefront i
+ * on the patch's i-th run of 128 sources; every run term is written to `exchange` with write-through stores, an arrival
+ * counter per (patch, tile) tells the wavefront that arrives last, and that one adds the terms in run order and finishes the
+ * tile.  No LDS and no barrier: the other patches of the launch run exactly as in the plain form, the launch's last
+ * resident set consists of items a third as long and the chip drains in a third of the time.  The drivers use k = 3 for
+ * launches below 8 10^9 pairs (profiles/r04_xch_ab.txt: -11 % at 16 of the bench's patches, -3.7 % at 32, -0.5 % at 128).
+ * dE and w_part do not depend on source_split (the same fp32 runs, the same fp64 additions); patches of more than 512
+ * points are evaluated by one wavefront per tile whatever source_split says, patches of <= 128 points are a single run -
+ * so a split pays only when the patches have 129..512 points (the drivers check that); without both tables a launch with
+ * source_split < 0 is the plain one.
+ * exchange: device scratch of at least dnp_patch_exchange_bytes(N, k) bytes (NULL / 0 with source_split = 1).  CONTRACT: the
+ * buffer is zero before its first use (dnp_exchange_init, or any memset); every launch leaves its arrival counters zero
+ * again, and a record's place in the buffer depends on its (patch, tile) index only, so one buffer serves launches of any
+ * size one after the other - on ONE stream at a time.  A launch with source_split < 0 and no (or too small a) buffer
+ * returns DNP_EWORKSPACE.
  * dE is bit-identical with dnp_patch_fields_boxed_f32's; w_part requires eps >= 1e-30 and both tables.
  */
 int64_t dnp_patch_tile_rows(void);
@@ -183,7 +190,10 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts,
                                const int64_t* patch_off, const int64_t* patch_idx, int64_t P,
                                const int64_t* point_patch, const float* patch_box, const float* tile_box,
                                int64_t p_begin, int64_t p_end, float eps,
-                               float* dE, double* w_part, int source_split, void* stream);
+                               float* dE, double* w_part, int source_split,
+                               void* exchange, size_t exchange_bytes, void* stream);
+size_t dnp_patch_exchange_bytes(int64_t N, int64_t split_patches);
+int dnp_exchange_init(void* exchange, size_t bytes, void* stream);
 /* W[k][j] = sum of w_part[k][i][slot] over the tiles i that overlap patch j (slot 0 when j is the patch of the tile's
  * first row), in tile order; W is [K, P] doubles.  Same quantity as dnp_interactions_f32 up to fp64 reassociation. */
 int dnp_interactions_from_tiles(const double* w_part, int64_t K, int64_t N, const int64_t* point_patch,

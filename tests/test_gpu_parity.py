@@ -422,12 +422,13 @@ def test_tile_tables_and_fused_interaction_rows(dev):
 
 
 def test_source_split_does_not_change_a_bit(dev):
-    """dnp_patch_fields_tiled_f32's source_split = 4 (the four wavefronts of a workgroup on one target tile, one
-    128-source run of the patch each, run terms through LDS, added in run order) and -k (one launch whose last k patches
-    are split, the others not) against 1: slabs and interaction
-    partials bit-identical - on the headline cloud's patches (all of 129..512 points) and on a cut with patches
-    outside that window (<= 128 points: a single run; > 512: one wavefront evaluates them whatever the split) - and
-    the split-4 slabs agree with the fp64 oracle.  The drivers' rule picks 4 for short launches only."""
+    """dnp_patch_fields_tiled_f32's source_split = -k (ONE launch whose last k patches are split items: four wavefronts
+    on one target tile, one 128-source run of the patch each, the run terms through the exchange buffer, added in run
+    order by whichever wavefront arrives last) against 1: slabs and interaction partials bit-identical - on the headline
+    cloud's patches (all of 129..512 points) and on a cut with patches outside that window (<= 128 points: a single run;
+    > 512: one wavefront evaluates them whatever the split) - and the all-split slabs agree with the fp64 oracle.  Every
+    launch reuses ONE exchange buffer (its counters re-arm themselves, a record's place does not depend on the launch's
+    size), and the outputs are poisoned first: a launch that never finished an item cannot pass on stale rows."""
     from tools.workloads import headline_workload
     pc, patches, _ = headline_workload()
     off, idx, sizes = util.patch_csr([p.to(dev) for p in patches], dev)
@@ -436,20 +437,37 @@ def test_source_split_does_not_change_a_bit(dev):
     assert sizes.min() > 128 and sizes.max() <= 512
     point_patch = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
     boxes, tiles = fu._patch_boxes(swork, off, None), fu._TileTables(swork, sizes)
-    assert fu._pick_source_split(sizes[:16], N) == -3 and fu._pick_source_split(sizes[:32], N) == -3 and fu._pick_source_split(sizes, N) == 1
+    assert fu._pick_source_split(sizes[:16], N) == -3 and fu._pick_source_split(sizes[:32], N) == -3
+    assert fu._pick_source_split(sizes[:128], N) == -3 and fu._pick_source_split(sizes, N) == 1
     assert fu._pick_source_split(np.array([100, 300]), N) == 1 and fu._pick_source_split(np.array([300, 600]), N) == 1
     res = {}
-    for ss in (1, 4, -1, -3, -7, -23, -24, -100):         # -k: ONE launch whose last k patches are split (k >= 24: all of them)
-        wp = torch.zeros((24, tiles.n_tiles, 2), dtype=torch.float64, device=dev)
+
+    def poison(shape):       # _patch_slabs returns torch.empty memory: make sure a launch that wrote nothing cannot pass on stale rows
+        torch.full(shape, float("nan"), dtype=torch.float32, device=dev)
+
+    for ss in (1, -1, -3, -7, -23, -24, -100, -2, -3):    # k >= 24: every patch of the range split
+        wp = torch.full((24, tiles.n_tiles, 2), float("nan"), dtype=torch.float64, device=dev)
+        poison((24, N, 3))
         res[ss] = (fu._patch_slabs(swork, off, None, point_patch, 40, 64, 1e-5, boxes, tiles.boxes, wp, ss), wp)
         assert torch.equal(res[1][0], res[ss][0]) and torch.equal(res[1][1], res[ss][1]), ss
+        poison((24, N, 3))
         assert torch.equal(fu._patch_slabs(swork, off, None, point_patch, 40, 64, 1e-5, boxes, tiles.boxes, None, ss), res[1][0]), ss
+    # the exchange buffer is left re-armed: every arrival counter zero again
+    xch = fu._exchange(1, dev)
+    item = int(_lib.load().dnp_patch_exchange_bytes(N, 1)) // tiles.n_tiles
+    assert int(xch[: 24 * tiles.n_tiles * item].view(-1, item)[:, :128].sum().item()) == 0
+    # a split launch without the buffer is refused, not run wrong
+    dE = torch.empty((24, N, 3), dtype=torch.float32, device=dev)
+    rc = _lib.load().dnp_patch_fields_tiled_f32(_lib.ptr(swork), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch), _lib.ptr(boxes),
+                                                _lib.ptr(tiles.boxes), 40, 64, 1e-5, _lib.ptr(dE), None, -3, None, 0,
+                                                _lib.current_stream())
+    assert rc == -3 and b"exchange buffer" in _lib.load().dnp_last_error()
     k = 51
     others = (point_patch != k).cpu()
     rows = torch.nonzero(others).flatten()[::53]
     lo, hi = int(off[k]), int(off[k + 1])
     ref = c_oracle.field_grad_f64(swork[lo:hi].cpu().numpy(), swork.cpu()[rows].numpy())
-    assert rel_rowwise(res[4][0][k - 40].cpu()[rows], ref) < TOL
+    assert rel_rowwise(res[-100][0][k - 40].cpu()[rows], ref) < TOL
     # patches outside the 2..4-run window, and a ragged last tile
     sizes2 = np.array([64, 128, 129, 300, 512, 513, 900, 41, 390, 2000], dtype=np.int64)
     off2 = t(np.concatenate([[0], np.cumsum(sizes2)])).to(dev)
@@ -459,10 +477,10 @@ def test_source_split_does_not_change_a_bit(dev):
                      torch.full((77,), -1, dtype=torch.int64, device=dev)])
     boxes2, tiles2 = fu._patch_boxes(sw2, off2, None), fu._TileTables(sw2, sizes2)
     a = fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, None, 1)
-    b = fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, None, 4)
-    assert torch.equal(a, b)
-    for tail in (-1, -2, -4, -9):
-        assert torch.equal(a, fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, None, tail)), tail
+    for tail in (-1, -2, -4, -9, -10, -50, -3):
+        poison(tuple(a.shape))
+        b = fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, None, tail)
+        assert torch.equal(a, b), tail
     for k in (1, 2, 5, 9):
         lo, hi = int(off2[k]), int(off2[k + 1])
         others = (pp2 != k).cpu()

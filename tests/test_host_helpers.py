@@ -240,7 +240,8 @@ def test_fused_interaction_rule_and_source_split_policy():
     big = np.full(256, 390)
     assert fu._pick_source_split(big, 100000) == 1 and fu._pick_source_split(big[:16], 100000) == -3
     assert fu._pick_source_split(big[:32], 100000) == -3                  # a rank's share of 8: 1.25e9 pairs
-    assert fu._pick_source_split(big[:48], 100000) == 1                   # 1.87e9 pairs: above the threshold
+    assert fu._pick_source_split(big[:128], 100000) == -3                 # a rank's share of 2: 5e9 pairs, still below the threshold
+    assert fu._pick_source_split(big[:210], 100000) == 1                  # 8.2e9 pairs: above it
     assert fu._pick_source_split(np.array([128, 300]), 1000) == 1 and fu._pick_source_split(np.array([129, 512]), 1000) == -3
     assert fu._pick_source_split(np.array([], dtype=np.int64), 1000) == 1
 

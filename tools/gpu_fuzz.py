@@ -2,7 +2,7 @@
 """Randomised cross-check of the round-3 entry points against the fp64 C oracle and against each other, for a time budget
 (default 180 s):  random clouds (clustered, with coincident points), random patch cuts (sizes 1 .. 700, empty patches, rows in
 no patch, ragged last tiles), random eps;
-  * dnp_patch_fields_tiled_f32 with / without the tile table, with / without interaction partials, source_split 1 / 4 / -k:
+  * dnp_patch_fields_tiled_f32 with / without the tile table, with / without interaction partials, source_split 1 / -k (split tail through the exchange buffer) / all split:
     slabs bit-identical in every combination, each slab row within 1e-5 of the oracle (rows of cancellation-heavy random
     clouds get the documented 16 u sum-of-terms allowance),
   * dnp_interactions_from_tiles against dnp_interactions_f32 where the tiles allow the fused form,
@@ -99,19 +99,20 @@ def run(budget=180.0, seed=0):
                 boxes, tiles = fu._patch_boxes(sw, off, None), fu._TileTables(sw, sizes)
                 base = fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes)
                 tail = -int(rng.integers(1, n_p + 2))             # one launch, its last k patches split (k > n_p: all of them)
-                wp = {ss: torch.zeros((n_p, tiles.n_tiles, 2), dtype=torch.float64, device=dev) for ss in (1, 4, tail)}
+                allp = -(n_p + 1)                                 # every patch of the launch split
+                wp = {ss: torch.full((n_p, tiles.n_tiles, 2), float("nan"), dtype=torch.float64, device=dev) for ss in (1, allp, tail)}
                 variants = {"tile table": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes),
                             "partials": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, wp[1], 1),
-                            "split 4": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, None, 4),
-                            "split 4 + partials": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, wp[4], 4),
+                            "all split": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, None, allp),
+                            "all split + partials": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, wp[allp], allp),
                             f"split {tail}": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, None, tail),
                             f"split {tail} + partials": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, wp[tail], tail),
                             "no boxes": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps)}
                 for name, v in variants.items():
                     if not torch.equal(v, base):
                         fails.append(f"case {cases}: slabs differ with '{name}' (sizes {sizes.tolist()}, loose {loose})")
-                if not torch.equal(wp[1], wp[4]) or not torch.equal(wp[1], wp[tail]):
-                    fails.append(f"case {cases}: partials differ between source_split 1, 4 and {tail} (sizes {sizes.tolist()})")
+                if not torch.equal(wp[1], wp[allp]) or not torch.equal(wp[1], wp[tail]):
+                    fails.append(f"case {cases}: partials differ between source_split 1, all split and {tail} (sizes {sizes.tolist()})")
                 if tiles.fused:
                     W3 = fu._interaction_rows(base, sw, off, None)
                     Wt = torch.empty_like(W3)

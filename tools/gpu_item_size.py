@@ -63,15 +63,15 @@ def main():
     w_part = torch.empty((P, tiles.n_tiles, 2), dtype=torch.float64, device=dev)
     ref = fu._patch_slabs(pts, off, None, point_patch, 0, 32, 1e-5, boxes, tiles.boxes, w_part[:32], 1)
     wref = w_part[:32].clone()
-    for ss in (4,):
+    for ss in (-32,):          # every patch split (round 4: through the exchange buffer; round 3's LDS form was source_split = 4)
         got = fu._patch_slabs(pts, off, None, point_patch, 0, 32, 1e-5, boxes, tiles.boxes, w_part[:32], ss)
         print(f"#   split {ss}: slabs bit-identical to split 1: {bool(torch.equal(got, ref))}, partials: {bool(torch.equal(w_part[:32], wref))}")
     for K in (16, 32, 64, 128, 256):
         line = f"K={K:4d}"
-        for ss in (1, 4):
+        for ss in (1, -K):
             med, mn = timed(lambda: fu._patch_slabs(pts, off, None, point_patch, 0, K, 1e-5, boxes, tiles.boxes, w_part[:K], ss),
                             reps=30 if K < 256 else 16)
-            line += f"   split{ss} {med:.4f} / {mn:.4f}"
+            line += f"   {'plain' if ss == 1 else 'all split'} {med:.4f} / {mn:.4f}"
         print(line, flush=True)
 
     print("# item size: every patch cut into `split` parts (same pairs, split x the items, 1/split the item length)")

@@ -148,7 +148,7 @@ def main():
     assert lib.dnp_tile_boxes_f32(_lib.ptr(pts), N, 6, 128, _lib.ptr(tile_boxes), stream) == 0
     dE = torch.empty((P, N, 3), dtype=torch.float32, device=dev)
     w_part = torch.empty((P, n_tiles, 2), dtype=torch.float64, device=dev)
-    for K, ss in ((32, 1), (32, 4), (64, 1), (256, 1)):
+    for K, ss in ((32, 1), (64, 1), (256, 1)):
         wgs = -(-N // (256 if ss == 1 else 128)) * K
         assert wgs * 4 <= stamps.shape[0]
         ms = []
@@ -158,7 +158,7 @@ def main():
             a.record()
             rc = lib.dnp_patch_fields_tiled_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch),
                                                 _lib.ptr(boxes), _lib.ptr(tile_boxes), 0, K, 1e-5, _lib.ptr(dE),
-                                                _lib.ptr(w_part), ss, stream)
+                                                _lib.ptr(w_part), ss, None, 0, stream)
             b.record()
             assert rc == 0
             torch.cuda.synchronize()
