@@ -10,9 +10,16 @@ A STEP is one pass of the data-parallel hot path over the cloud: every one of th
 field evaluations `field_grad(pts[patch_k], pts[~patch_k])` (dnp_patch_fields_tiled_f32 - all of them in
 one launch per rank, the per-tile interaction partials out of the same kernel's epilogue), the patch
 interaction matrix rows (dnp_interactions_from_tiles) and, for N > 1, the RCCL all-gather of those rows
-that hands rank 0 everything the sequential greedy loop needs - exactly what the drivers do
-(field_utils._slabs_and_rows).  After the timed steps the gathered matrix is run through the device
-greedy loop and compared with the REFERENCE's own trace on this cloud (tests/golden/G19).
+that hands every rank what the sequential greedy loop needs - IN THE LAUNCH STREAM'S ORDER, exactly as the
+product's sharded driver issues it (parallel.sharded_patch_propagation -> field_utils._batched_patch_propagation:
+slabs -> W rows -> synchronous parallel.gather_rows -> greedy loop; the greedy loop needs all of W, so the
+driver cannot overlap the collective with anything).  `value` and `ms_per_step` are THAT step.  At N > 1 over
+RCCL a second timed loop runs the same steps with the all-gather issued asynchronously (two in flight, each
+overlapping the next step's pair kernel: what parallel.sharded_patch_propagation_many reaches when it is handed
+several clouds) and reports it as `value_pipelined` / `ms_per_step_pipelined` - never as `value`; the gathered
+matrix of the pipelined loop is compared with the in-order one (`pipelined_matches_in_order`).  After the timed
+steps the gathered matrix is run through the device greedy loop and compared with the REFERENCE's own trace on
+this cloud (tests/golden/G19).
 Patches are sharded over the ranks in contiguous size-balanced blocks, so the total work is fixed
 as N grows ("strong").  Inputs are resident in HBM before the timed region.  `value` counts the
 algorithmic pairs sum_k |patch_k| * (N - |patch_k|) of all ranks per second of the slowest rank.
@@ -23,6 +30,8 @@ Also printed on the same JSON line:
                 launch_ms <= ms_per_step is asserted); `hbm` carries the algorithmic HBM GB/s the metric
                 name asks for (<< 1 % of 8 TB/s by construction).
   step_parts    pair kernel / interaction kernel / all-gather times of a step; per_rank at N > 1.
+  sharded_driver (N > 1) the whole product call parallel.sharded_patch_propagation(diffuse=True) on this cloud: slabs,
+                W rows, all-gather, greedy loop, fp64 combine, the all-reduce of the partial fields, tail - what a caller gets.
   clock_warmup  the untimed steps run before the W warm-up steps (80 ms of load: a device climbs to its
                 sustained clock in ~50 ms, and at N ranks a step is N times shorter).
   cpu_baseline  the oracle's dense-broadcast PyTorch port of the reference path, timed on this
@@ -205,10 +214,12 @@ def main():
         p_lo, p_hi = int(fb[0]), int(fb[1])
     my_pairs = float((sizes[p_lo:p_hi] * (N_POINTS - sizes[p_lo:p_hi])).sum())
     split = fu._pick_source_split(sizes[p_lo:p_hi], N_POINTS)     # the drivers' rule: short launches split their items
-    # N > 1 over RCCL: the W-row all-gather is asynchronous (BENCH_SYNC_GATHER=1 keeps it in the launch stream's order)
-    overlap_gather = world > 1 and backend == "nccl" and not os.environ.get("BENCH_SYNC_GATHER")
+    # The headline step gathers in the launch stream's order (what the product's driver does).  At N > 1 over RCCL a second
+    # timed loop overlaps the all-gather with the next step's pair kernel (BENCH_NO_PIPELINED=1 skips it; BENCH_PIPELINED=1
+    # forces it on other backends / one rank, where gather_rows_async falls back to the in-order form).
+    can_pipeline = (world > 1 and backend == "nccl" and not os.environ.get("BENCH_NO_PIPELINED")) or bool(os.environ.get("BENCH_PIPELINED"))
     pending = []
-    overlap_state = {"on": overlap_gather}
+    overlap_state = {"on": False, "async_seen": False}
 
     # HIP events on the stream the kernels are launched on (torch's current stream = what _lib.current_stream() hands
     # to the C ABI), recorded INSIDE the timed steps: the pair kernel's duration, the interaction kernel's and the
@@ -233,9 +244,9 @@ def main():
         if marks is not None and marks[2] is not None:
             marks[2].record()
         if overlap_state["on"]:
-            # the all-gather of this step's W rows runs on RCCL's stream and overlaps the NEXT step's pair kernel (the
-            # steps are independent batches); two in flight at most: the gather of step i - 2 is consumed before step i
-            # issues its own.  marks[2..3] then time the enqueue only.
+            # pipelined loop only: the all-gather of this step's W rows runs on RCCL's stream and overlaps the NEXT step's pair
+            # kernel (the steps are independent batches); two in flight at most: the gather of step i - 2 is consumed before
+            # step i issues its own
             try:
                 W, work = parallel.gather_rows_async(W, bounds)
             except Exception as exc:           # never lose a scaling run to the overlap: fall back to the in-order gather
@@ -243,6 +254,7 @@ def main():
                 overlap_state["on"] = False
                 W, work = parallel.gather_rows(W, bounds), None
             if work is not None:
+                overlap_state["async_seen"] = True
                 pending.append((W, work))
                 while len(pending) > 2:
                     pending.pop(0)[1].wait()
@@ -302,6 +314,32 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
+    W_in_order = W
+
+    # ---- the same steps with the all-gather overlapped (N > 1 over RCCL): reported beside the headline, never as it ---
+    pipelined = None
+    if can_pipeline:
+        overlap_state["on"] = True
+        for _ in range(max(args.warmup, 4)):
+            W = step()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            W = step()
+        fence()
+        el2 = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el2], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el2 = float(tmax.item())
+        same = bool(torch.equal(W, W_in_order))
+        if world > 1:
+            ok = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            same = bool(int(ok.item()))
+        pipelined = {"ms_per_step": el2 / args.steps * 1e3, "asynchronous": overlap_state["async_seen"], "matches_in_order": same}
+        overlap_state["on"] = False
+        W = W_in_order
     # developer aid BENCH_FAKE_WORLD: only one rank's share was computed, so only that share is credited
     value = (my_pairs if (fake > 1 and world == 1) else pairs_total) * args.steps / elapsed
 
@@ -332,7 +370,7 @@ def main():
                   "interactions_from": "pair-kernel epilogue partials + dnp_interactions_from_tiles" if tiles.fused
                   else "dnp_interactions_f32 (second pass over the slabs)",
                   "gather_rows_ms": float(ag_all.mean()),
-                  "gather_rows_timed": "enqueue only: the all-gather is asynchronous" if overlap_state["on"] else "in the launch stream's order"}
+                  "gather_rows_timed": "in the launch stream's order (the product's sharded driver)"}
     per_rank = None
     if world > 1:
         # so that a scaling run explains itself: every rank's kernel time and its wait in the all-gather
@@ -345,7 +383,7 @@ def main():
                      "gather_rows_ms_min": float(t[4]), "pairs": float(t[5])} for r, t in enumerate(allr)]
     # HBM traffic cannot be read inside the run (PMC counters need rocprofv3): it is PROFILE-DERIVED, from the
     # committed summary of `rocprofv3 --pmc` passes over this same command, and says so
-    for prof_name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for prof_name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         prof = os.path.join(ROOT, "profiles", prof_name)
         if os.path.exists(prof) and world == 1 and not fake:
             try:
@@ -379,6 +417,34 @@ def main():
                 np.array_equal(order, g19["order"]) and np.array_equal(sigma[order[1:]] < 0, g19["flipped"][1:]))
             chosen_dev = float(np.max(np.abs(chosen.cpu().numpy() - g19["chosen"]) / np.abs(g19["chosen"])))
 
+    # ---- N > 1: the whole product call, every rank in it (what a caller of parallel.sharded_patch_propagation gets) ------
+    sharded_driver = None
+    if world > 1 and not args.headline_only:
+        ranges = util.PatchList(torch.arange(N_POINTS, device=dev), sizes, disjoint=True)
+        plist = list(enumerate(ranges))
+
+        def call():
+            parallel.sharded_patch_propagation(pts.clone(), plist, ranges, diffuse=True)
+        for _ in range(3):
+            call()
+        fence()
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call()
+        fence()
+        el3 = time.perf_counter() - t0
+        tmax = torch.tensor([el3], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tr = fu.last_trace("sharded")
+        ok_trace = None
+        g19_path = os.path.join(ROOT, "tests", "golden", "G19_headline_sphere_patch_propagation.npz")
+        if os.path.exists(g19_path):
+            ok_trace = bool(np.array_equal(np.asarray(tr["order"]), np.load(g19_path)["order"]))
+        sharded_driver = {"call": "parallel.sharded_patch_propagation(pts, patches, patches, diffuse=True)", "ms": float(tmax.item()) / reps * 1e3,
+                          "repetitions": reps, "includes": "layout, box tables, slabs + W rows, all-gather, greedy loop, fp64 combine, "
+                          "all-reduce of the partial fields, tail", "order_matches_reference_G19": ok_trace}
+
     out = None
     if rank == 0:
         out = {"metric": "dipole field-evals/sec (N x N pairs), 100k pts", "value": value, "unit": "pairs/s",
@@ -392,12 +458,23 @@ def main():
                                       "config 4)", "points": N_POINTS,
                           "patches": N_PATCHES, "pairs_per_step": pairs_total,
                           "parallelism": f"patch-sharded x{world}, " + ("RCCL" if backend == "nccl" else backend) +
-                                         " all-gather of W rows" +
-                                         (" (asynchronous, two in flight: overlaps the next step's pair kernel)" if overlap_state["on"] else "")},
+                                         " all-gather of W rows, in the launch stream's order"},
                "roofline": roofline, "hbm": hbm, "step_parts": step_parts, "signs_ok": signs_ok,
                "trace_matches_reference_G19": trace_matches_reference, "chosen_max_rel_dev_vs_G19": chosen_dev}
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if pipelined is not None:
+            # NOT the headline: the step with its all-gather overlapped with the next step's pair kernel - what a caller that
+            # hands parallel.sharded_patch_propagation_many several clouds reaches; one cloud at a time cannot (the greedy
+            # loop needs all of W)
+            pv = (my_pairs if (fake > 1 and world == 1) else pairs_total) / (pipelined["ms_per_step"] * 1e-3)
+            out["value_pipelined"] = pv if pipelined["asynchronous"] else None
+            out["ms_per_step_pipelined"] = pipelined["ms_per_step"] if pipelined["asynchronous"] else None
+            out["pipelined_matches_in_order"] = pipelined["matches_in_order"]
+            out["pipelined_note"] = ("all-gather of step i overlaps the pair kernel of step i + 1 (two in flight)" if pipelined["asynchronous"]
+                                     else "this backend stages through the host: the asynchronous form fell back to the in-order gather")
+        if sharded_driver is not None:
+            out["sharded_driver"] = sharded_driver
         if fake > 1 and world == 1:
             out["fake_world"] = fake          # NOT a measurement of `fake` GPUs: one rank's share on one GPU
         if world > 1 and backend != "nccl":

@@ -44,6 +44,7 @@ SIGNATURES = {
                                                   ctypes.c_float, _c_p, _c_p, ctypes.c_int, _c_p, _c_sz, _c_p]),
     "dnp_patch_exchange_bytes": (_c_sz, [_c_i64, _c_i64]),
     "dnp_exchange_init": (ctypes.c_int, [_c_p, _c_sz, _c_p]),
+    "dnp_check_tile_groups": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_p]),
     "dnp_interactions_from_tiles": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p]),
     "dnp_interactions_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p]),
     "dnp_combine_fields_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, ctypes.c_int, _c_p]),
@@ -88,9 +89,16 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH):
-            # a fresh checkout: compile the HIP library once (hipcc is part of the ROCm image); there is no
-            # CPU fallback, so a failed build is an error, not a degradation
+        stale = False
+        if "DNP_LIB" not in os.environ and os.path.exists(LIB_PATH):
+            try:                                        # a source edited after the last build: never run yesterday's kernels
+                from . import build as _build
+                stale = _build.needs_build()
+            except Exception:
+                stale = False
+        if not os.path.exists(LIB_PATH) or stale:
+            # a fresh checkout (or an edited source): compile the HIP library (hipcc is part of the ROCm image); there is
+            # no CPU fallback, so a failed build is an error, not a degradation
             if "DNP_LIB" in os.environ:
                 raise DnpError(f"DNP_LIB={LIB_PATH} does not exist")
             try:

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const ReduceArgs<F> a,
 }
 
 template <typename F, int MODE>
-static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
+static int run_pairs_body(const F* src, int64_t S, int64_t ld_src, const int64_t* src_idx,
                      const F* tgt, int64_t T, int64_t ld_tgt, const int64_t* tgt_idx,
                      F eps, int64_t max_pts, F* out, int64_t ld_out, int out_scatter, int accumulate,
                      int* nonfinite, int* nonfinite_host, void* workspace, size_t workspace_bytes, hipStream_t stream,
@@ -405,6 +405,11 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
         // already amortised and the two extra launches cost what the tables save; profiles/r03_k1_tables_ab.txt.)
         pa.far_d2 = ((double)S * (double)T >= DNP_K1_FAR_FROM) ? (F)far_threshold_d2((double)eps) : F(0);
         for (int i = 0; i <= n_chunks; ++i) pa.chunk_off[i] = r.chunk_off[i];
+#ifdef DNP_BOUNDS
+        pa.bnd = PairBounds{};
+        pa.bnd.n_partial = (int64_t)(workspace_bytes / sizeof(double)); pa.bnd.n_src_rows = src_idx ? INT64_MAX : S;
+        pa.bnd.err = bounds_err_buffer();
+#endif
         const dim3 grid((unsigned)t_tiles, (unsigned)n_chunks);
         // eps > 0 (what every caller of the reference passes): the short chain; otherwise the explicit one
         const int variant = (MODE != kField) ? kFast : (eps > F(0) ? kFast : (eps == F(0) ? kNanCoinc : kRobust));
@@ -447,6 +452,9 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
 #undef DNP_LAUNCH_PAIR
         DNP_CHECK_HIP(hipGetLastError());
         if (direct) break;
+#ifdef DNP_SKIP_REDUCE     // experiment builds only (wrong results): the call WITHOUT its second pass - the upper bound of what
+        continue;          // an in-kernel reduction by the last-arriving workgroup could save (profiles/r04_inkernel_reduce_bound.txt)
+#endif
 
         ReduceArgs<F> ra{};
         ra.partial = (const double*)workspace; ra.T = T; ra.tgt_idx = tgt_idx; ra.out = out; ra.ld_out = ld_out;
@@ -472,6 +480,32 @@ static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src
     return DNP_OK;
 }
 
+// the planner allocates (std::vector): no exception may leave the entry points (dnp_common.h, guarded)
+template <typename F, int MODE>
+static int run_pairs(const F* src, int64_t S, int64_t ld_src, const int64_t* src_idx, const F* tgt, int64_t T, int64_t ld_tgt,
+                     const int64_t* tgt_idx, F eps, int64_t max_pts, F* out, int64_t ld_out, int out_scatter, int accumulate,
+                     int* nonfinite, int* nonfinite_host, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                     int tail = 0, F* tgt_rw = nullptr) {
+    return guarded("field / potential launch", [&]() {
+        return run_pairs_body<F, MODE>(src, S, ld_src, src_idx, tgt, T, ld_tgt, tgt_idx, eps, max_pts, out, ld_out, out_scatter,
+                                       accumulate, nonfinite, nonfinite_host, workspace, workspace_bytes, stream, tail, tgt_rw);
+    });
+}
+
+// bytes of partial slab a call of this shape can ask for: the maximum over every plan run_pairs may choose - the scalar
+// kernel unsplit and source-split (the split plan's chunk rule is its own; round-3 advisor: nothing guaranteed that its
+// chunk count stayed below the unsplit plan's) and the LDS kernel
+static size_t workspace_for(int64_t S, int64_t T, int64_t max_pts, int nc) {
+    size_t best = 256;
+    for (int variant = 0; variant < 3; ++variant) {
+        const bool scalar = variant != 2;
+        const int split = variant == 1 ? DNP_K1_SPLIT : 1;
+        const size_t b = plan_workspace(make_plan(S, T, max_pts, nc, sizeof(double), scalar, split), T, nc, sizeof(double));
+        best = b > best ? b : best;
+    }
+    return best;
+}
+
 }  // namespace dnp
 
 using namespace dnp;
@@ -480,17 +514,17 @@ extern "C" {
 
 size_t dnp_field_grad_workspace_bytes(int64_t S, int64_t T, int64_t max_pts) {
     if (S <= 0 || T <= 0) return 256;
-    // chunk sums are kept in fp64 for both precisions; the answer covers both kernels (with / without src_idx)
-    const size_t a = plan_workspace(make_plan(S, T, max_pts, 3, sizeof(double), true), T, 3, sizeof(double));
-    const size_t b = plan_workspace(make_plan(S, T, max_pts, 3, sizeof(double), false), T, 3, sizeof(double));
-    return a > b ? a : b;
+    // chunk sums are kept in fp64 for both precisions; 0 = the planner itself ran out of host memory (dnp_last_error)
+    size_t bytes = 0;
+    const int rc = guarded("dnp_field_grad_workspace_bytes", [&]() { bytes = workspace_for(S, T, max_pts, 3); return (int)DNP_OK; });
+    return rc == DNP_OK ? bytes : 0;
 }
 
 size_t dnp_potential_workspace_bytes(int64_t S, int64_t T, int64_t max_pts) {
     if (S <= 0 || T <= 0) return 256;
-    const size_t a = plan_workspace(make_plan(S, T, max_pts, 1, sizeof(double), true), T, 1, sizeof(double));
-    const size_t b = plan_workspace(make_plan(S, T, max_pts, 1, sizeof(double), false), T, 1, sizeof(double));
-    return a > b ? a : b;
+    size_t bytes = 0;
+    const int rc = guarded("dnp_potential_workspace_bytes", [&]() { bytes = workspace_for(S, T, max_pts, 1); return (int)DNP_OK; });
+    return rc == DNP_OK ? bytes : 0;
 }
 
 int dnp_field_grad_f32(const float* src, int64_t S, int64_t ld_src, const int64_t* src_idx,

@@ -47,8 +47,13 @@ __global__ __launch_bounds__(256) void interactions_kernel(const float* __restri
         const int64_t t = patch_idx ? patch_idx[i] : i;   // nullptr: patches are contiguous row ranges
         const float* e = slab + t * 3;
         const float* n = pts + t * ld_pts + 3;
-        // per-point dot in fp32 like (E[patch] * pts[patch, 3:]).sum(dim=-1), patch sum in fp64
-        const float d = e[0] * n[0] + e[1] * n[1] + e[2] * n[2];
+        // per-point dot in fp32 like (E[patch] * pts[patch, 3:]).sum(dim=-1) - products rounded separately, added left to
+        // right, no fma contraction (the same statement as the pair kernel's epilogue) -, patch sum in fp64
+        float d;
+        {
+#pragma clang fp contract(off)
+            d = (e[0] * n[0] + e[1] * n[1]) + e[2] * n[2];
+        }
         s += (double)d;
     }
     // wave reduce (64 lanes), then across the 4 waves through LDS
@@ -141,9 +146,41 @@ __global__ __launch_bounds__(256) void tile_interactions_kernel(const double* __
     W[k * P + j] = s;
 }
 
+// the precondition of the pair kernel's interaction partials (w_part): the rows of a target tile take at most TWO group
+// values (the epilogue files a row under "the group of the tile's first row" or "the other one").  One thread per tile;
+// violations[0] += tiles that hold three or more.
+__global__ __launch_bounds__(256) void tile_groups_kernel(const int64_t* __restrict__ point_patch, int64_t N, int rows_per_tile,
+                                                          int64_t n_tiles, int32_t* __restrict__ violations) {
+    const int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= n_tiles) return;
+    const int64_t r0 = tile * rows_per_tile, r1 = (r0 + rows_per_tile < N) ? r0 + rows_per_tile : N;
+    const int64_t first = point_patch[r0];
+    int64_t second = first;
+    bool bad = false;
+    for (int64_t r = r0 + 1; r < r1; ++r) {
+        const int64_t v = point_patch[r];
+        if (v == first || v == second) continue;
+        if (second == first) second = v; else bad = true;
+    }
+    if (bad) atomicAdd(violations, 1);
+}
+
 }  // namespace dnp
 
 extern "C" {
+
+int dnp_check_tile_groups(const int64_t* point_patch, int64_t N, int32_t* violations, void* stream) {
+    clear_error();
+    DNP_REQUIRE(N >= 0, "negative size");
+    if (N == 0) return DNP_OK;
+    DNP_REQUIRE(point_patch && violations, "NULL pointer");
+    const int rows = 64 * kPatchScalarKT;
+    const int64_t n_tiles = ceil_div(N, (int64_t)rows);
+    hipLaunchKernelGGL(tile_groups_kernel, dim3((unsigned)ceil_div(n_tiles, 256)), dim3(256), 0, (hipStream_t)stream, point_patch,
+                       N, rows, n_tiles, violations);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
 
 int dnp_tile_boxes_f32(const float* pts, int64_t N, int64_t ld_pts, int64_t rows_per_tile, float* boxes, void* stream) {
     clear_error();
@@ -251,6 +288,15 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
         pa.far_d2 = DNP_FAR_D2;
 #endif
         const hipStream_t st = (hipStream_t)stream;
+#ifdef DNP_BOUNDS
+        {
+            const int64_t n_tiles_b = ceil_div(N, (int64_t)64 * kPatchScalarKT);
+            pa.bnd.n_chunk_off = P + 1; pa.bnd.n_chunk_box = patch_box ? P : 0; pa.bnd.n_tile_box = tile_box ? n_tiles_b : 0;
+            pa.bnd.n_tgt_group = N; pa.bnd.n_w_part = w_part ? kn * n_tiles_b * 2 : 0; pa.bnd.n_partial = kn * N * 3;
+            pa.bnd.n_xch_items = exchange ? (int64_t)(exchange_bytes / (size_t)xch_item_bytes(4, kPatchScalarKT, 3)) : 0;
+            pa.bnd.n_src_rows = N; pa.bnd.err = bounds_err_buffer();
+        }
+#endif
         if (scalar_path) {
             // patch-sorted cloud (what the drivers pass): contiguous sources -> the scalar-unit kernel
             const bool tabled = patch_box && tile_box && kPatchFar && pa.far_d2 > 0.f;

@@ -528,8 +528,8 @@ int dnp_patch_finish_f32(const float* work, int64_t ld_work, int64_t N, const in
 }
 
 // ---- host: merge of small voxel cells ---------------------------------------------------------------------------
-int dnp_merge_cells(const int32_t* cell_ijk, const int64_t* cell_size, int64_t C, int64_t min_patch,
-                    int64_t* seq, int64_t* seq_off, int64_t* n_out, int32_t* sweeps_out) {
+static int merge_cells_body(const int32_t* cell_ijk, const int64_t* cell_size, int64_t C, int64_t min_patch,
+                            int64_t* seq, int64_t* seq_off, int64_t* n_out, int32_t* sweeps_out) {
     clear_error();
     DNP_REQUIRE(C >= 0, "negative C");
     DNP_REQUIRE(seq_off && n_out, "NULL output pointer");
@@ -591,6 +591,12 @@ int dnp_merge_cells(const int32_t* cell_ijk, const int64_t* cell_size, int64_t C
     *n_out = n;
     if (sweeps_out) *sweeps_out = sweeps;
     return DNP_OK;
+}
+
+// the merge allocates (hash map, per-cell member lists): nothing may leave the boundary as an exception
+int dnp_merge_cells(const int32_t* cell_ijk, const int64_t* cell_size, int64_t C, int64_t min_patch,
+                    int64_t* seq, int64_t* seq_off, int64_t* n_out, int32_t* sweeps_out) {
+    return guarded("dnp_merge_cells", [&]() { return merge_cells_body(cell_ijk, cell_size, C, min_patch, seq, seq_off, n_out, sweeps_out); });
 }
 
 }  // extern "C"

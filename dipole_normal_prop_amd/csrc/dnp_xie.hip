@@ -6,8 +6,8 @@
 // not divided when |r| == 0 (so a coincident pair yields n_s itself), and its projection on the target
 // normal M[t][s] = ref[t][s] . n_t with NaN/Inf -> 0.  The OUTPUT is the whole T x S matrix (4 or 12 bytes per pair):
 // lanes run along the source index so that every store instruction writes 256 contiguous bytes of a row, targets are
-// staged through LDS and broadcast.  The arithmetic is the reference's IEEE op order bit for bit (sqrt, divisions, no fma
-// contraction) instead of the rsq/rcp chain of pair_kernel.h: the ordered propagation takes sign decisions on row sums of
+// staged through LDS and broadcast.  The arithmetic is the reference's IEEE op order bit for bit for normal-range operands
+// (sqrt, divisions, no fma contraction; see Recip for the one caveat) instead of the rsq/rcp chain of pair_kernel.h: the ordered propagation takes sign decisions on row sums of
 // this matrix.  Measured (profiles/r03_xie_time.txt): the tensor form is bound by its HBM writes (4.5-5.6 TB/s), the
 // matrix form by that arithmetic (2 TB/s written, 510 Gpairs/s) - see Recip and ieee_sqrt below for what it costs.
 //
@@ -46,8 +46,12 @@ __device__ inline double ieee_sqrt(double x) { return __builtin_sqrt(x); }
 // quotient, and the pair body divides three numbers by |R| and three by |R|^3.  Outside the exponent extremes (where
 // div_scale rescales and div_fixup patches) that expansion IS  r = rcp(b); r += r (1 - b r);  q = a r;  q += r (a - b q)
 // twice - so the refined reciprocal is computed once per denominator and every quotient costs five instructions, with the
-// same bits as the compiler's division for operands in the normal range (checked against a -DDNP_XIE_IEEE_DIV=1 build on
-// 10^8 pairs, tools/gpu_xie_time.py).  fp64 keeps the compiler's division (its expansion differs; that form is not timed).
+// same bits as the compiler's division WHEN DENOMINATOR, NUMERATOR AND QUOTIENT ARE IN THE NORMAL RANGE (checked against a
+// -DDNP_XIE_IEEE_DIV=1 build on 10^8 pairs, tools/gpu_xie_time.py).  The kernel guards the denominator (|R| outside [1e-10,
+// 1e10] takes the compiler's division); a DENORMAL numerator or quotient - a coordinate difference or a normal component
+// below 1e-38, which fp32 coordinates in the unit box cannot produce (their differences are 0 or >= 2^-25 apart) - skips
+// div_scale / div_fixup here and may round differently from a / b: the bit-for-bit statement is for normal-range operands.
+// fp64 keeps the compiler's division (its expansion differs; that form is not timed).
 #ifndef DNP_XIE_IEEE_DIV
 #define DNP_XIE_IEEE_DIV 0
 #endif
@@ -167,6 +171,10 @@ __global__ __launch_bounds__(kOrderThreads) void xie_order_reg_kernel(const floa
     float w[VPT], cur[VPT], nxt[VPT];
 #pragma unroll
     for (int k = 0; k < VPT; ++k) { w[k] = 0.f; nxt[k] = 0.f; }
+    // interactions = torch.zeros(T, N) in the reference (field_utils.py:581): an order row that is not a full permutation
+    // (a repeated index) leaves entries unvisited, and they must read 0, not whatever the caller's buffer held (round-3
+    // advisor: field_utils passes torch.empty).  The stores of the loop below come after the loop's first barrier.
+    for (int64_t j = tid; j < N; j += kOrderThreads) out[j] = 0.f;
     auto fetch = [&](int64_t idx, float (&dst)[VPT]) {
         const float* row = M + idx * N;
 #pragma unroll

@@ -125,6 +125,36 @@ constexpr int64_t xch_item_bytes(int ss, int kt, int nc) { return 128 + (int64_t
 
 enum PairMode { kField = 0, kPotential = 1 };
 
+// -DDNP_BOUNDS builds (tools/bin/libdnp_bounds.so: tests/test_gpu_bounds.py and tools/gpu_fuzz.py run against it): every read
+// or write of a table whose index does not come from the lane's own bounds test - the wave-uniform tables (chunk offsets,
+// chunk / target-tile boxes, the group of a tile's first row), the per-tile partials, the exchange records, the partial slab -
+// is checked against the table's LENGTH, which the launchers pass in PairArgs::bnd; an index outside is COUNTED in a device
+// error word (dnp_debug_bounds_errors) and clamped, so the check build reports where the product build would have read past
+// a table - a fault only when the table happens to end on a page boundary (round 3's fuzz seed 7: the last workgroup's
+// target-less wavefronts read the tile-box table up to 72 bytes past its end).  The product build has none of this.
+struct PairBounds {
+    int64_t n_chunk_off;     // entries of chunk_off_dev (patch mode: P + 1)
+    int64_t n_chunk_box;     // rows of chunk_box
+    int64_t n_tile_box;      // rows of tile_box
+    int64_t n_tgt_group;     // entries of tgt_group
+    int64_t n_w_part;        // doubles of w_part
+    int64_t n_partial;       // elements of partial
+    int64_t n_xch_items;     // records of the exchange buffer
+    int64_t n_src_rows;      // rows of src
+    unsigned int* err;       // [8] counters by table (kBnd*)
+};
+enum { kBndChunkOff = 0, kBndChunkBox = 1, kBndTileBox = 2, kBndTgtGroup = 3, kBndWPart = 4, kBndPartial = 5, kBndXch = 6, kBndSrc = 7 };
+#ifdef DNP_BOUNDS
+__device__ inline int64_t bounds_checked(int64_t idx, int64_t len, int code, unsigned int* err) {
+    if (idx >= 0 && idx < len) return idx;
+    if (err) atomicAdd(err + code, 1u);
+    return idx < 0 || len <= 0 ? 0 : len - 1;
+}
+#define DNP_BND(idx, field, code) bounds_checked((int64_t)(idx), a.bnd.field, code, a.bnd.err)
+#else
+#define DNP_BND(idx, field, code) (idx)
+#endif
+
 template <typename F, typename PT = F>
 struct PairArgs {
     const F* src;            // [*, ld_src] rows (x,y,z,px,py,pz)
@@ -156,6 +186,9 @@ struct PairArgs {
     // their counters in the same words: zero before the first launch, left zero by every launch.
     unsigned int* xch_ticket;  // = the buffer; item i's counter is xch_ticket[i * xch_item_bytes / 4]
     double* xch_terms;         // = the buffer + 128 bytes; item i's terms start at xch_terms[i * xch_item_bytes / 8]
+#ifdef DNP_BOUNDS
+    PairBounds bnd;
+#endif
     int32_t chunk_off[kMaxChunks + 1];  // by-value CSR offsets when chunk_off_dev == nullptr
 };
 
@@ -333,12 +366,18 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
     const int64_t chunk = blockIdx.y;
     int64_t s_begin, s_end;
     if (a.chunk_off_dev) {
-        s_begin = a.chunk_off_dev[a.chunk_base + chunk];
-        s_end = a.chunk_off_dev[a.chunk_base + chunk + 1];
+        s_begin = a.chunk_off_dev[DNP_BND(a.chunk_base + chunk, n_chunk_off, kBndChunkOff)];
+        s_end = a.chunk_off_dev[DNP_BND(a.chunk_base + chunk + 1, n_chunk_off, kBndChunkOff)];
     } else {
         s_begin = a.chunk_off[chunk];
         s_end = a.chunk_off[chunk + 1];
     }
+#ifdef DNP_BOUNDS   // the source range comes from a caller's table: it must lie inside the source rows
+    if (s_begin < 0 || s_begin > s_end || s_end > a.bnd.n_src_rows) {
+        if (a.bnd.err && (threadIdx.x & 63) == 0) atomicAdd(a.bnd.err + kBndSrc, 1u);
+        s_begin = s_end = 0;
+    }
+#endif
     const int64_t tile_base = (int64_t)blockIdx.x * (kBlock * KT);
 
     // ---- this lane's targets ---------------------------------------------------------------
@@ -462,7 +501,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
         const int64_t t = tile_base + k * kBlock + tid;
         if (t < a.T) {
             bool excluded = false;
-            if (a.tgt_group) excluded = (a.tgt_group[trow[k]] == chunk_id);
+            if (a.tgt_group) excluded = (a.tgt_group[DNP_BND(trow[k], n_tgt_group, kBndTgtGroup)] == chunk_id);
             if (a.out) {
                 // single chunk, single leaf: the second pass would only filter and copy - do it here
                 F* o = a.out + (a.out_scatter ? trow[k] : t) * a.ld_out;
@@ -476,7 +515,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
                     o[c] = a.accumulate ? (F)(o[c] + v) : v;
                 }
             } else {
-                PT* o = a.partial + ((int64_t)chunk * a.T + t) * NC;
+                PT* o = a.partial + DNP_BND(((int64_t)chunk * a.T + t) * NC, n_partial - (NC - 1), kBndPartial);
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     PT v = (PT)((MODE == kField) ? -acc[k][c] : acc[k][c]);
@@ -664,12 +703,18 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
     }
     int64_t s_begin, s_end;
     if (a.chunk_off_dev) {
-        s_begin = a.chunk_off_dev[a.chunk_base + chunk];
-        s_end = a.chunk_off_dev[a.chunk_base + chunk + 1];
+        s_begin = a.chunk_off_dev[DNP_BND(a.chunk_base + chunk, n_chunk_off, kBndChunkOff)];
+        s_end = a.chunk_off_dev[DNP_BND(a.chunk_base + chunk + 1, n_chunk_off, kBndChunkOff)];
     } else {
         s_begin = a.chunk_off[chunk];
         s_end = a.chunk_off[chunk + 1];
     }
+#ifdef DNP_BOUNDS   // the source range comes from a caller's table: it must lie inside the source rows
+    if (s_begin < 0 || s_begin > s_end || s_end > a.bnd.n_src_rows) {
+        if (a.bnd.err && (threadIdx.x & 63) == 0) atomicAdd(a.bnd.err + kBndSrc, 1u);
+        s_begin = s_end = 0;
+    }
+#endif
     const int64_t tile_base = (int64_t)bx * (ktg * 64 * KT);
     F tx[KT], ty[KT], tz[KT];
     int64_t trow[KT];
@@ -737,8 +782,12 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
             // as a memory access fault when the table ended on a page boundary)
             const int64_t n_tiles = (a.T + 64 * KT - 1) / (64 * KT);
             int64_t wave_tile = (int64_t)bx * ktg + __builtin_amdgcn_readfirstlane(tg);
+#ifndef DNP_BUG_A8D48F5   // (defined only by the regression build of tests/test_gpu_bounds.py: the kernel as it was before the fix)
             wave_tile = wave_tile < n_tiles ? wave_tile : n_tiles - 1;
-            const F* tb = a.tile_box + wave_tile * 6;                       // wave-uniform: scalar loads
+#else
+            (void)n_tiles;
+#endif
+            const F* tb = a.tile_box + DNP_BND(wave_tile, n_tile_box, kBndTileBox) * 6;    // wave-uniform: scalar loads
 #pragma unroll
             for (int c = 0; c < 3; ++c) { tlo[c] = tb[c]; thi[c] = tb[3 + c]; }
         } else {
@@ -763,7 +812,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
                 d2box = M::fma(gap, gap, d2box);
             }
         } else if constexpr (given) {
-            const F* b = a.chunk_box + (a.chunk_base + chunk) * 6;          // wave-uniform: scalar loads
+            const F* b = a.chunk_box + DNP_BND(a.chunk_base + chunk, n_chunk_box, kBndChunkBox) * 6;   // wave-uniform: scalar loads
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 F gap = b[c] - thi[c];
@@ -872,6 +921,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
             } else {
                 // publish this run's term: write-through stores (512 contiguous bytes per instruction), then the ticket
                 constexpr int64_t kItemDoubles = xch_item_bytes(SS, KT, NC) / 8, kItemWords = xch_item_bytes(SS, KT, NC) / 4;
+                xch_item = DNP_BND(xch_item, n_xch_items, kBndXch);
                 unsigned int* ticket = a.xch_ticket + xch_item * kItemWords;
                 double* slot = a.xch_terms + xch_item * kItemDoubles + (sp * (KT * NC)) * 64 + (tid & 63);
 #pragma unroll
@@ -943,7 +993,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
     int64_t g_first = 0;
     if constexpr (WPART) {                                  // group of the tile's first target (wave-uniform)
         const int row0 = __builtin_amdgcn_readfirstlane((int)trow[0]);
-        g_first = row0 >= 0 ? a.tgt_group[row0] : -2;
+        g_first = row0 >= 0 ? a.tgt_group[DNP_BND(row0, n_tgt_group, kBndTgtGroup)] : -2;
     }
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
@@ -951,7 +1001,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
         if (t < a.T) {
             bool excluded = false;
             int64_t grp = -1;
-            if (a.tgt_group) { grp = a.tgt_group[trow[k]]; excluded = (grp == chunk_id); }
+            if (a.tgt_group) { grp = a.tgt_group[DNP_BND(trow[k], n_tgt_group, kBndTgtGroup)]; excluded = (grp == chunk_id); }
             if (a.out) {
                 F* o = a.out + (a.out_scatter ? trow[k] : t) * a.ld_out;
 #pragma unroll
@@ -964,7 +1014,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
                     o[c] = a.accumulate ? (F)(o[c] + v) : v;
                 }
             } else {
-                PT* o = a.partial + ((int64_t)chunk * a.T + t) * NC;
+                PT* o = a.partial + DNP_BND(((int64_t)chunk * a.T + t) * NC, n_partial - (NC - 1), kBndPartial);
                 PT vv[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
@@ -975,13 +1025,37 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
                 }
                 if constexpr (WPART && MODE == kField) {
                     // per-point dot in fp32 like (E[patch] * pts[patch, 3:]).sum(dim=-1) (field_utils.py:316), patch sums in fp64
+                    // (products rounded separately, added left to right - no fma contraction: W from this epilogue, W from
+                    // interactions_kernel and torch's elementwise product + sum must not depend on a compiler's choice)
                     const F* n = a.tgt + trow[k] * a.ld_tgt + 3;
-                    const float d = (float)vv[0] * n[0] + (float)vv[1] * n[1] + (float)vv[2] * n[2];
+                    float d;
+                    {
+#pragma clang fp contract(off)
+                        d = ((float)vv[0] * n[0] + (float)vv[1] * n[1]) + (float)vv[2] * n[2];
+                    }
                     if (grp == g_first) w_first += (double)d; else w_other += (double)d;
                 }
             }
         }
     }
+#ifdef DNP_BOUNDS    // WPART's precondition: the tile's rows take at most two group values (else w_other mixes patches)
+    if constexpr (WPART && MODE == kField) {
+        int64_t other = -9;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const int64_t t = tile_base + (int64_t)tg * (64 * KT) + k * 64 + (tid & 63);
+            if (t < a.T) { const int64_t gq = a.tgt_group[DNP_BND(trow[k], n_tgt_group, kBndTgtGroup)]; if (gq != g_first) other = gq; }
+        }
+        const int64_t omax = wave_max<int64_t>(other);
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const int64_t t = tile_base + (int64_t)tg * (64 * KT) + k * 64 + (tid & 63);
+            if (t < a.T) { const int64_t gq = a.tgt_group[DNP_BND(trow[k], n_tgt_group, kBndTgtGroup)]; bad |= (gq != g_first && gq != omax); }
+        }
+        if (__any(bad) && (tid & 63) == 0 && a.bnd.err) atomicAdd(a.bnd.err + kBndWPart, 1u);
+    }
+#endif
     if constexpr (WPART && MODE == kField) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {             // fixed butterfly: the sums do not depend on anything but the tile
@@ -991,7 +1065,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
         const int64_t n_tiles = (a.T + 64 * KT - 1) / (64 * KT);
         const int64_t wave_tile = (int64_t)bx * ktg + tg;
         if ((tid & 63) == 0 && wave_tile < n_tiles) {
-            double* wp = a.w_part + ((int64_t)chunk * n_tiles + wave_tile) * 2;
+            double* wp = a.w_part + DNP_BND(((int64_t)chunk * n_tiles + wave_tile) * 2, n_w_part - 1, kBndWPart);
             wp[0] = w_first;
             wp[1] = w_other;
         }

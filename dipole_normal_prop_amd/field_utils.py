@@ -817,17 +817,18 @@ def _listed_patches(patches, all_patches, dev) -> Optional[torch.Tensor]:
     return util.to_device(flags, dev)
 
 
-def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tensor, diffuse: bool,
-                               eps: float = 1e-5, want_E: bool = True, shard=None):
-    """Core of the batched drivers on a device cloud `work[N,6]` (normals already weight-scaled); everything
-    stays on the device - no host synchronisation between the launches.
+class _BatchedWork:
+    """What _batched_begin leaves for _batched_end: the sorted cloud, the tables, this rank's W rows and the slab blocks
+    kept for the diffuse combine."""
+    __slots__ = ("swork", "perm", "point_patch", "off", "sizes", "boxes", "tiles", "bounds", "p_lo", "p_hi", "batch", "kept",
+                 "W_local", "diffuse", "want_E", "eps")
 
-    Returns a _Batched: device tensors order / sigma / chosen; Es[N,3] = this rank's part of the accumulated
-    field of the diffuse form (fp64 sum of the sigma-signed fp32 slabs) in PATCH-SORTED row order (None unless
-    want_E and diffuse); perm (sorted row -> caller's row), the sorted working cloud and patch ids, and
 
-    `shard` = (rank, world, gather_fn): patches are split over ranks in contiguous size-balanced blocks, each
-    rank computes its slabs and W rows, gather_fn(rows, bounds) returns the full W on every rank."""
+def _batched_begin(work: torch.Tensor, patches, diffuse: bool, eps: float = 1e-5, want_E: bool = True,
+                   rank: int = 0, world: int = 1) -> "_BatchedWork":
+    """First half of the batched drivers on a device cloud `work[N,6]` (normals already weight-scaled): the patch-sorted
+    layout, the box tables, this rank's slabs and its rows of W - everything that does not need the other ranks.  No host
+    synchronisation; the second half is _batched_end."""
     dev = work.device
     N = work.shape[0]
     off, idx, sizes = util.patch_csr(patches, dev)
@@ -857,7 +858,6 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
             point_patch = torch.cat([point_patch, torch.full((loose.shape[0],), -1, dtype=torch.int64, device=dev)])
         swork = work[perm].contiguous()
 
-    rank, world, gather = (0, 1, None) if shard is None else shard
     # contiguous blocks of patches per rank, balanced by pair count |patch| * N
     bounds = _balanced_blocks(sizes, world)
     p_lo, p_hi = int(bounds[rank]), int(bounds[rank + 1])
@@ -891,32 +891,59 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
             kept[b0] = dE
             kept_bytes += (b1 - b0) * per_slab
         del dE
+    bw = _BatchedWork()
+    bw.swork, bw.perm, bw.point_patch, bw.off, bw.sizes, bw.boxes, bw.tiles = swork, perm, point_patch, off, sizes, boxes, tiles
+    bw.bounds, bw.p_lo, bw.p_hi, bw.batch, bw.kept = bounds, p_lo, p_hi, batch, kept
+    bw.diffuse, bw.want_E, bw.eps = diffuse, want_E, eps
     if len(W_rows) == 1:
-        W_local = W_rows[0]
+        bw.W_local = W_rows[0]
     else:
-        W_local = torch.cat(W_rows, dim=0) if W_rows else torch.zeros((0, P), dtype=torch.float64, device=dev)
-    W_full = W_local if gather is None else gather(W_local, bounds)
-    order, sigma, chosen = _greedy_on_device(W_full, start_t)
+        bw.W_local = torch.cat(W_rows, dim=0) if W_rows else torch.zeros((0, P), dtype=torch.float64, device=dev)
+    return bw
 
+
+def _batched_end(bw: "_BatchedWork", W_full: torch.Tensor, start_t: torch.Tensor) -> "_Batched":
+    """Second half: the greedy loop on the full W and, for the diffuse form, this rank's fp64 partial field."""
+    dev = bw.swork.device
+    N = bw.swork.shape[0]
+    order, sigma, chosen = _greedy_on_device(W_full, start_t)
     E64 = None
-    if want_E and diffuse:
+    if bw.want_E and bw.diffuse:
         # E = sum_k sigma_k dE_k (field_utils.py:330-331).  The reference adds the fp32 slabs one by one in
         # visit order; here the signed slabs are summed in fp64 and rounded to fp32 once, which is closer to the
         # exact sum and does not depend on the visit order or on how the patches are split over GPUs.
         Es = torch.empty((N, 3), dtype=torch.float64, device=dev)
         first = True
-        for b0 in range(p_lo, p_hi, batch):
-            b1 = min(b0 + batch, p_hi)
-            dE = kept.pop(b0, None)
+        for b0 in range(bw.p_lo, bw.p_hi, bw.batch):
+            b1 = min(b0 + bw.batch, bw.p_hi)
+            dE = bw.kept.pop(b0, None)
             if dE is None:
-                dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, None if tiles is None else tiles.boxes)
+                dE = _patch_slabs(bw.swork, bw.off, None, bw.point_patch, b0, b1, bw.eps, bw.boxes,
+                                  None if bw.tiles is None else bw.tiles.boxes)
             _combine_signed(dE, sigma, b0, Es, not first)
             first = False
             del dE
         if first:
             Es.zero_()
         E64 = Es
-    return _Batched(order, sigma, chosen, E64, perm, swork, point_patch)
+    return _Batched(order, sigma, chosen, E64, bw.perm, bw.swork, bw.point_patch)
+
+
+def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tensor, diffuse: bool,
+                               eps: float = 1e-5, want_E: bool = True, shard=None):
+    """Core of the batched drivers on a device cloud `work[N,6]` (normals already weight-scaled); everything
+    stays on the device - no host synchronisation between the launches.
+
+    Returns a _Batched: device tensors order / sigma / chosen; Es[N,3] = this rank's part of the accumulated
+    field of the diffuse form (fp64 sum of the sigma-signed fp32 slabs) in PATCH-SORTED row order (None unless
+    want_E and diffuse); perm (sorted row -> caller's row), the sorted working cloud and patch ids, and
+
+    `shard` = (rank, world, gather_fn): patches are split over ranks in contiguous size-balanced blocks, each
+    rank computes its slabs and W rows, gather_fn(rows, bounds) returns the full W on every rank."""
+    rank, world, gather = (0, 1, None) if shard is None else shard
+    bw = _batched_begin(work, patches, diffuse, eps, want_E, rank, world)
+    W_full = bw.W_local if gather is None else gather(bw.W_local, bw.bounds)
+    return _batched_end(bw, W_full, start_t)
 
 
 def _free_device_bytes(dev) -> int:

@@ -107,11 +107,29 @@ def agree_on_start(start_t: torch.Tensor, group=None) -> torch.Tensor:
     return start_t
 
 
+def _finish_sharded(fu, pts, work, w, st, patches, diffuse, listed, start_t):
+    """Tail of a sharded propagation once the greedy loop has run: the all-reduce of the partial fields (diffuse) and the
+    stores into the caller's tensor."""
+    if diffuse and st.Es is not None:
+        st.Es = reduce_field(st.Es)                 # patch-sorted rows: the same permutation on every rank
+    if not diffuse or listed is not None:
+        fu._finish_batched(pts, st, diffuse, listed, w)
+    else:
+        flip = torch.where(st.point_patch >= 0, st.sigma[st.point_patch.clamp(min=0)], 1.0).to(torch.float32)
+        work[:, 3:] = work[:, 3:] * flip[:, None]
+        fu._diffuse_sign_pass(work, st.field().to(torch.float32), [patch for _, patch in patches])
+        fu._finish_patch_driver(pts, work, w)
+    fu._set_trace("sharded", order=st.order, sigma=st.sigma, chosen=st.chosen, start=start_t)
+
+
 def sharded_patch_propagation(pts: torch.Tensor, patches, all_patches, diffuse=False, weights=None,
                               start_patch: Optional[int] = None):
     """strongest_field_propagation (field_utils.py:286-348) with the per-patch fields sharded over
     the ranks of the default process group.  Every rank must call it with the same arguments; every
-    rank ends with the same oriented normals in `pts` (in place).  Trace: field_utils.last_trace("sharded")."""
+    rank ends with the same oriented normals in `pts` (in place).  Trace: field_utils.last_trace("sharded").
+
+    The collectives are issued in the launch stream's order: the greedy loop needs ALL of W, so for one cloud there is
+    nothing to overlap the all-gather with (sharded_patch_propagation_many does, across clouds)."""
     from . import field_utils as fu
 
     rank, size = world()
@@ -122,13 +140,58 @@ def sharded_patch_propagation(pts: torch.Tensor, patches, all_patches, diffuse=F
         start_t = agree_on_start(fu._start_tensor(work, all_patches, start_patch))
         listed = fu._listed_patches(patches, all_patches, work.device) if diffuse else None
         st = fu._batched_patch_propagation(work, all_patches, start_t, diffuse, shard=(rank, size, gather_rows))
-        if diffuse and st.Es is not None:
-            st.Es = reduce_field(st.Es)                 # patch-sorted rows: the same permutation on every rank
-        if not diffuse or listed is not None:
-            fu._finish_batched(pts, st, diffuse, listed, w)
-        else:
-            flip = torch.where(st.point_patch >= 0, st.sigma[st.point_patch.clamp(min=0)], 1.0).to(torch.float32)
-            work[:, 3:] = work[:, 3:] * flip[:, None]
-            fu._diffuse_sign_pass(work, st.field().to(torch.float32), [patch for _, patch in patches])
-            fu._finish_patch_driver(pts, work, w)
-        fu._set_trace("sharded", order=st.order, sigma=st.sigma, chosen=st.chosen, start=start_t)
+        _finish_sharded(fu, pts, work, w, st, patches, diffuse, listed, start_t)
+
+
+def sharded_patch_propagation_many(jobs, diffuse=False):
+    """sharded_patch_propagation for SEVERAL clouds, pipelined: `jobs` is a sequence of (pts, patches, all_patches) or
+    (pts, patches, all_patches, weights, start_patch) tuples, every rank passes the same sequence, every `pts` is oriented in
+    place.  Returns the list of traces (order / sigma / chosen / start as numpy arrays), one per job.
+
+    One cloud cannot hide its all-gather - the greedy loop needs all of W - but a queue of clouds can: the W rows of cloud
+    i are gathered on the collective library's own stream (gather_rows_async) while this rank's pair kernel of cloud i + 1
+    runs, and cloud i's greedy loop, combine and tail follow behind it.  The start patches of all jobs are agreed on with
+    ONE broadcast up front (a per-job broadcast would queue behind the asynchronous gather of the next job and pull it onto
+    the critical path); the diffuse form's all-reduce of the partial fields stays in stream order.  Results are those of
+    sharded_patch_propagation job by job (bit for bit); where the backend stages through the host (gloo) or blocks are
+    unequal, the gather falls back to the in-order form and only the launch order differs."""
+    from . import field_utils as fu
+
+    rank, size = world()
+    traces = []
+    with torch.no_grad():
+        norm = []
+        for job in jobs:
+            pts, patches, all_patches = job[0], job[1], job[2]
+            weights = job[3] if len(job) > 3 else None
+            start_patch = job[4] if len(job) > 4 else None
+            norm.append((pts, patches, all_patches, weights, start_patch))
+        live = [j for j in norm if len(j[2]) > 0]
+        if not live:
+            return traces
+        prepared = [fu._prepare_work(pts, weights) for pts, _, _, weights, _ in live]
+        starts = torch.cat([fu._start_tensor(work, all_patches, start_patch).reshape(1)
+                            for (work, _), (_, _, all_patches, _, start_patch) in zip(prepared, live)])
+        starts = agree_on_start(starts)
+
+        def finish(item):
+            i, bw, W, handle = item
+            pts, patches, all_patches, _, _ = live[i]
+            work, w = prepared[i]
+            if handle is not None:
+                handle.wait()                       # a stream-side wait: the host does not block
+            start_t = starts[i:i + 1]
+            st = fu._batched_end(bw, W, start_t)
+            listed = fu._listed_patches(patches, all_patches, work.device) if diffuse else None
+            _finish_sharded(fu, pts, work, w, st, patches, diffuse, listed, start_t)
+            traces.append(fu.last_trace("sharded"))
+
+        pending = None
+        for i, (pts, patches, all_patches, _, _) in enumerate(live):
+            bw = fu._batched_begin(prepared[i][0], all_patches, diffuse, rank=rank, world=size)
+            W, handle = gather_rows_async(bw.W_local, bw.bounds)
+            if pending is not None:
+                finish(pending)
+            pending = (i, bw, W, handle)
+        finish(pending)
+    return traces

@@ -19,7 +19,8 @@
  *     no entry point synchronises the device or allocates device memory.  Scratch comes
  *     from the caller: ask dnp_*_workspace_bytes() and pass a buffer of at least that size.
  *   - return value: 0 = ok, negative = DNP_E* below; a message for the calling thread is
- *     available from dnp_last_error().  The library never aborts and is re-entrant
+ *     available from dnp_last_error().  The library never aborts, lets no C++ exception cross this boundary (host-side
+ *     allocation failures come back as DNP_ENOMEM; the *_workspace_bytes queries return 0 then) and is re-entrant
  *     (the reference calls field_grad concurrently from Python threads, util.py:187-196).
  */
 #ifndef DNP_H
@@ -39,7 +40,9 @@ enum {
     DNP_EINVAL = -1,    /* bad argument (NULL pointer, negative size, ld too small ...) */
     DNP_ENODEV = -2,    /* no HIP device / not a gfx950 code object for this device */
     DNP_EWORKSPACE = -3,/* workspace missing or too small */
-    DNP_EHIP = -4       /* a HIP runtime call failed; see dnp_last_error() */
+    DNP_EHIP = -4,      /* a HIP runtime call failed; see dnp_last_error() */
+    DNP_ENOMEM = -5,    /* a host-side allocation failed (launch planner, cell merge) */
+    DNP_EINTERNAL = -6  /* an unexpected C++ exception was caught at the boundary; see dnp_last_error() */
 };
 
 /* ---- housekeeping ------------------------------------------------------------------- */
@@ -194,6 +197,12 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts,
                                void* exchange, size_t exchange_bytes, void* stream);
 size_t dnp_patch_exchange_bytes(int64_t N, int64_t split_patches);
 int dnp_exchange_init(void* exchange, size_t bytes, void* stream);
+/* The precondition of w_part, checked on the device for callers that cannot check it from patch sizes on the host (the
+ * Python drivers do that: field_utils._tiles_within_two_groups): violations[0] (a device int32, NOT cleared here) += the
+ * number of target tiles of dnp_patch_tile_rows() rows whose rows take three or more values of point_patch.  Nonzero means
+ * w_part would be wrong for those tiles - use dnp_interactions_f32 on the slabs instead.  No synchronisation: read the
+ * counter behind the stream.  (A -DDNP_BOUNDS build of the library checks the same inside the pair kernel.) */
+int dnp_check_tile_groups(const int64_t* point_patch, int64_t N, int32_t* violations, void* stream);
 /* W[k][j] = sum of w_part[k][i][slot] over the tiles i that overlap patch j (slot 0 when j is the patch of the tile's
  * first row), in tile order; W is [K, P] doubles.  Same quantity as dnp_interactions_f32 up to fp64 reassociation. */
 int dnp_interactions_from_tiles(const double* w_part, int64_t K, int64_t N, const int64_t* point_patch,

@@ -2,15 +2,34 @@
 // GPU sanitizers are not available on the pool).  Built and run by tests/test_host_sanitized.py.
 //   dnp_xyz_parse_f32 / dnp_xyz_format_f32: random bytes, random number-alphabet text and mutated well-formed rows in
 //     exact-size heap buffers (an over-read trips ASan); every accepted text must survive format -> parse unchanged.
-//   dnp_merge_cells: random voxel sets against a brute-force restatement of the merge rule (include/dnp.h).
+//   dnp_merge_cells: random voxel sets against a brute-force restatement of the merge rule (include/dnp.h); bad tables
+//     (coordinates outside [0, 2^20), NULL pointers, negative counts) are refused with DNP_EINVAL.
+//   the extern "C" contract (round 4): with operator new made to FAIL after a random number of allocations, dnp_merge_cells
+//     and the launch planner behind dnp_field_grad_workspace_bytes / dnp_potential_workspace_bytes return DNP_ENOMEM / 0 -
+//     no exception leaves the library; the planner is also run over random shapes (its index arithmetic under ASan).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <random>
 #include <string>
 #include <vector>
 
 #include "dnp.h"
+
+// ---- allocation-failure injection: the g_fail_in-th operator new from now on throws std::bad_alloc (0 = never) ------
+static long g_fail_in = 0;
+void* operator new(size_t n) {
+    if (g_fail_in > 0 && --g_fail_in == 0) throw std::bad_alloc();
+    void* p = malloc(n ? n : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void* operator new[](size_t n) { return operator new(n); }
+void operator delete(void* p) noexcept { free(p); }
+void operator delete[](void* p) noexcept { free(p); }
+void operator delete(void* p, size_t) noexcept { free(p); }
+void operator delete[](void* p, size_t) noexcept { free(p); }
 
 static int fuzz_text(std::mt19937_64& rng, int iterations) {
     const char alphabet[] = "0123456789.eE+- \n\t\rnaif_x";
@@ -191,10 +210,75 @@ static int fuzz_merge(std::mt19937_64& rng, int iterations) {
     return 0;
 }
 
+static int fuzz_merge_refusals() {
+    int32_t ijk[6] = {0, 0, 0, 1, 0, 0};
+    int64_t sz[2] = {5, 5}, seq[2], off[3], n = -7;
+    int bad = 0;
+    bad += dnp_merge_cells(ijk, sz, -1, 10, seq, off, &n, nullptr) != DNP_EINVAL;
+    bad += dnp_merge_cells(nullptr, sz, 2, 10, seq, off, &n, nullptr) != DNP_EINVAL;
+    bad += dnp_merge_cells(ijk, sz, 2, 10, seq, nullptr, &n, nullptr) != DNP_EINVAL;
+    ijk[4] = 1 << 20;
+    bad += dnp_merge_cells(ijk, sz, 2, 10, seq, off, &n, nullptr) != DNP_EINVAL;
+    ijk[4] = -1;
+    bad += dnp_merge_cells(ijk, sz, 2, 10, seq, off, &n, nullptr) != DNP_EINVAL;
+    bad += strlen(dnp_last_error()) == 0;
+    ijk[4] = 0;
+    bad += dnp_merge_cells(ijk, sz, 0, 10, nullptr, off, &n, nullptr) != DNP_OK || n != 0;     // an empty table is fine
+    if (bad) { printf("merge: %d refusal checks failed\n", bad); return 1; }
+    printf("merge: bad tables are refused\n");
+    return 0;
+}
+
+static int fuzz_alloc_failures(std::mt19937_64& rng, int iterations) {
+    // a fixed table of 64 cells; operator new fails at a random point of the call
+    std::vector<int32_t> ijk;
+    std::vector<int64_t> sz;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            for (int k = 0; k < 4; ++k) { ijk.insert(ijk.end(), {i, j, k}); sz.push_back(3 + (i + j + k) % 5); }
+    std::vector<int64_t> seq(sz.size()), off(sz.size() + 1);
+    int enomem = 0, ok = 0;
+    for (int it = 0; it < iterations; ++it) {
+        int64_t n = -1;
+        g_fail_in = 1 + (long)(rng() % 200);
+        const int rc = dnp_merge_cells(ijk.data(), sz.data(), (int64_t)sz.size(), 12, seq.data(), off.data(), &n, nullptr);
+        g_fail_in = 0;
+        if (rc == DNP_ENOMEM) ++enomem;
+        else if (rc == DNP_OK) ++ok;
+        else { printf("alloc: dnp_merge_cells returned %d under allocation failure\n", rc); return 1; }
+    }
+    int zero = 0, sized = 0;
+    for (int it = 0; it < iterations; ++it) {
+        const int64_t S = 1 + (int64_t)(rng() % 400000), T = 1 + (int64_t)(rng() % 400000);
+        g_fail_in = 1 + (long)(rng() % 12);
+        const size_t a = (it & 1) ? dnp_field_grad_workspace_bytes(S, T, 15000) : dnp_potential_workspace_bytes(S, T, (it & 2) ? 0 : 15000);
+        g_fail_in = 0;
+        if (a == 0) { ++zero; if (strlen(dnp_last_error()) == 0) { printf("alloc: no message with a 0 answer\n"); return 1; } }
+        else ++sized;
+    }
+    if (enomem == 0 || zero == 0) { printf("alloc: the injection never hit (%d, %d)\n", enomem, zero); return 1; }
+    printf("alloc: %d merges / %d planner calls answered DNP_ENOMEM / 0 under allocation failure (%d / %d completed); nothing escaped\n",
+           enomem, zero, ok, sized);
+    // the planner over random shapes, no failures: every answer is a plausible size
+    for (int it = 0; it < iterations * 4; ++it) {
+        const int64_t S = (int64_t)(rng() % 3000000), T = (int64_t)(rng() % 3000000);
+        const int64_t max_pts = (rng() & 3) ? 15000 : (int64_t)(rng() % 40000) - 5;
+        const size_t a = dnp_field_grad_workspace_bytes(S, T, max_pts), b = dnp_potential_workspace_bytes(S, T, max_pts);
+        if (a < 256 || b < 256 || a > ((size_t)5 << 30) || b > ((size_t)5 << 30)) {
+            printf("planner: workspace %zu / %zu for S=%lld T=%lld max_pts=%lld\n", a, b, (long long)S, (long long)T, (long long)max_pts);
+            return 1;
+        }
+    }
+    printf("planner: %d random shapes sized\n", iterations * 4);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const int scale = argc > 1 ? atoi(argv[1]) : 1;
     std::mt19937_64 rng(1234);
     if (fuzz_text(rng, 40000 * scale)) return 1;
     if (fuzz_merge(rng, 300 * scale)) return 1;
+    if (fuzz_merge_refusals()) return 1;
+    if (fuzz_alloc_failures(rng, 300 * scale)) return 1;
     return 0;
 }

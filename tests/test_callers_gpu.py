@@ -208,9 +208,9 @@ def test_config5_reference_field_at_headline_size(dev):
     keep = ((out6.cpu()[:, 3:] * tgt6[:, 3:]).sum(-1) > 0).numpy()
     ref_keep = np.unpackbits(g["keep"])[:N].astype(bool)
     E = fu.field_grad(src_d, tgt3.to(dev)).cpu().numpy()
-    differ = np.nonzero(keep != ref_keep)[0]
-    # a decision may differ only where the reference's E.n is itself rounding noise of its fp32 sum over 10^5 sources
-    assert len(differ) <= 5 and np.all(np.abs(g["e_dot_n"][differ]) <= 1e-5 * np.linalg.norm(E[differ], axis=1)), differ
+    # every one of the 100 000 decisions is the reference's (measured in round 4: 0 differ, profiles/r04_sign_slack.txt;
+    # rounds 2-3 had allowed 5 noise-level exceptions without recording that none was used)
+    assert np.array_equal(keep, ref_keep), np.nonzero(keep != ref_keep)[0]
     rows = g["rows"]
     scale = np.linalg.norm(g["E_rows"], axis=1, keepdims=True)
     assert (np.abs(E[rows] - g["E_rows"]) / scale).max() < 1e-5

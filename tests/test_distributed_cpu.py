@@ -100,6 +100,56 @@ def _worker(rank, world, port, start, q):
         dist.destroy_process_group()
 
 
+def _worker_many(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        cloud, patches = _case()
+        from dipole_normal_prop_amd import field_utils as fu
+        fu._patch_slabs, fu._interaction_rows = OracleStandIn.slabs, OracleStandIn.interactions
+        fu._patch_boxes = lambda work, off, idx: None
+        fu._TileTables = lambda swork, sizes: None
+        fu._greedy_on_device, fu._combine_signed = OracleStandIn.greedy, OracleStandIn.combine_signed
+        fu._finish_batched = OracleStandIn.finish
+        fu._prepare_work = lambda p, w: (p.detach().clone().float(), None)
+        flipped = cloud.clone()
+        flipped[patches[2], 3:] *= -1                      # a second, different cloud: one more patch turned over
+        a, b, c = cloud.clone(), flipped.clone(), cloud.clone()
+        jobs = [(a, list(enumerate(patches)), patches, None, 3), (b, list(enumerate(patches)), patches),
+                (c, list(enumerate(patches)), patches)]
+        traces = parallel.sharded_patch_propagation_many(jobs, diffuse=True)
+        q.put((rank, [t[:, 3:].numpy().copy() for t in (a, b, c)], [(tr["order"].copy(), tr["start"]) for tr in traces]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_many_clouds_pipelined_equal_the_one_by_one_results():
+    """parallel.sharded_patch_propagation_many on two gloo ranks (the gather falls back to the in-order form there: what is
+    exercised is the two-stage control flow - begin of job i + 1 before the end of job i, ONE start broadcast for all jobs):
+    three jobs, pinned and default starts, two different clouds; every job must equal the oracle's single-process run."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_many, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    cloud, patches = _case()
+    flipped = cloud.clone()
+    flipped[patches[2], 3:] *= -1
+    want = [O.strongest_field_propagation(c, list(enumerate(patches)), patches, diffuse=True, start_patch=s)
+            for c, s in ((cloud, 3), (flipped, None), (cloud, None))]
+    for rank, normals, traces in res:
+        assert len(traces) == 3
+        for (ref_pts, ref_tr), got_n, (order, start) in zip(want, normals, traces):
+            assert start == int(ref_tr["order"][0])
+            assert np.array_equal(order, ref_tr["order"])
+            assert np.array_equal(got_n, ref_pts[:, 3:].numpy())
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -172,3 +172,32 @@ def test_eight_way_split_of_the_headline_workload_is_bit_identical(dev):
         E_sum += part
     assert torch.equal(torch.cat(rows), W_all)
     assert torch.equal(E_sum.float(), E_one.float())
+
+
+def test_many_clouds_pipelined_on_the_device_equal_the_single_calls(dev):
+    """parallel.sharded_patch_propagation_many with the real kernels (one process: the two-stage order of the launches -
+    begin of cloud i + 1 before the end of cloud i - on one stream): all eight G6 variants' clouds as ONE queue per diffuse
+    flag; every cloud ends with the normals of its own strongest_field_propagation call, bit for bit, and its trace is
+    the reference's."""
+    from dipole_normal_prop_amd import field_utils as fu
+    from dipole_normal_prop_amd import parallel
+    g = load_golden("G6_patch_propagation")
+    allp = [p.to(dev) for p in csr_to_list(g["patch_off"], g["patch_idx"])]
+    patches = [(int(i), allp[int(i)]) for i in g["filtered"]]
+    for dflag in ("n", "d"):
+        tags = [t for t in ALL_G6 if t.split("_")[1] == dflag]
+        jobs, singles = [], []
+        for tag in tags:
+            cname, _, wflag = tag.split("_")
+            cloud = torch.from_numpy(g["pc_patchflip"] if cname == "pf" else g["pc_scrambled"])
+            w = torch.from_numpy(g["weights"]).to(dev) if wflag == "w" else None
+            jobs.append((cloud.clone().to(dev), patches, allp, w))
+            one = cloud.clone().to(dev)
+            fu.strongest_field_propagation(one, patches, allp, diffuse=(dflag == "d"), weights=w)
+            singles.append(one)
+        traces = parallel.sharded_patch_propagation_many(jobs, diffuse=(dflag == "d"))
+        assert len(traces) == len(tags)
+        for tag, job, one, tr in zip(tags, jobs, singles, traces):
+            assert np.array_equal(tr["order"], g[f"order_{tag}"]), tag
+            assert np.array_equal((tr["sigma"] < 0)[tr["order"]], g[f"flipped_{tag}"]), tag
+            assert torch.equal(job[0], one), tag

@@ -421,6 +421,30 @@ def test_tile_tables_and_fused_interaction_rows(dev):
     assert float((W[k - 7] - want).abs().max()) <= 1e-6 * float(want.abs().max())
 
 
+def test_tile_group_precondition_is_checkable_on_the_device(dev):
+    """dnp_check_tile_groups: the precondition of the fused interaction partials (every 128-row tile inside at most two
+    groups) counted on the device, for callers of the raw C ABI that have no patch sizes on the host (round-3 verdict:
+    dnp_patch_fields_tiled_f32 trusted the caller - a wrong W, silently).  A cut that satisfies it: 0, and W from the tiles
+    equals W from the slabs; a cut with a 20-row patch inside a tile: counted, and the host rule agrees."""
+    lib = _lib.require_device()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1000, 3, generator=g)
+    pc = torch.cat([0.4 * x / x.norm(dim=1, keepdim=True), x / x.norm(dim=1, keepdim=True)], 1).to(dev)
+    for sizes, want_ok in ((np.array([300, 200, 380, 120]), True), (np.array([300, 100, 20, 300, 280]), False)):
+        off = t(np.concatenate([[0], np.cumsum(sizes)])).to(dev)
+        pp = torch.repeat_interleave(torch.arange(len(sizes), device=dev), off[1:] - off[:-1])
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        assert lib.dnp_check_tile_groups(_lib.ptr(pp), 1000, _lib.ptr(bad), _lib.current_stream()) == 0
+        assert (int(bad.item()) == 0) == want_ok
+        assert fu._tiles_within_two_groups(sizes, 1000, 128) == want_ok
+        boxes, tiles = fu._patch_boxes(pc, off, None), fu._TileTables(pc, sizes)
+        assert tiles.fused == want_ok
+        if want_ok:
+            dE, W = fu._slabs_and_rows(pc, off, pp, 0, len(sizes), 1e-5, boxes, tiles, sizes)
+            W3 = fu._interaction_rows(dE, pc, off, None)
+            assert float((W - W3).abs().max()) <= 1e-12 * float(W3.abs().max())
+
+
 def test_source_split_does_not_change_a_bit(dev):
     """dnp_patch_fields_tiled_f32's source_split = -k (ONE launch whose last k patches are split items: four wavefronts
     on one target tile, one 128-source run of the patch each, the run terms through the exchange buffer, added in run

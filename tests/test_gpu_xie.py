@@ -44,87 +44,38 @@ def test_xie_interaction_matrix_rows_on_ok_subsample(dev):
     assert np.array_equal(np.diag(M.cpu().numpy()), (g["pc"][:, 3:] ** 2).sum(-1).astype(np.float32))   # self pair: n.n
 
 
-def _noise_level_decisions(M, order, ref_flip, got_flip):
-    """Every decision where `got` differs from the reference must be one the reference itself took on rounding
-    noise: with the weights of the points visited before it (the reference's), the row sum in fp64 is below
-    2e-6 of the sum of the magnitudes (fp32 summation error of ~1000 terms)."""
-    w = np.zeros(M.shape[0])
-    for i in order:
-        if got_flip[i] != ref_flip[i]:
-            terms = M[i].astype(np.float64) * w
-            assert abs(terms.sum()) <= 2e-6 * np.abs(terms).sum(), (i, terms.sum(), np.abs(terms).sum())
-        w[i] = -1.0 if ref_flip[i] else 1.0
-
-
-def _consistent_with_the_reference(M, orders, ref_n, got_n, ref_d=None, got_d=None):
-    """The complete noise argument for the ordered propagation, both phases, per visiting order r:
-    ordered phase - every decision that differs from the reference's is one the reference took on rounding noise
-    (_noise_level_decisions, with the reference's weights);
-    diffuse phase (interactions = M @ weights with the FINAL weights, field_utils.py:597-603) - every decision of the
-    kernel path equals the sign of the exact (fp64) row sum with the kernel path's own weights unless that sum is itself
-    noise, and wherever it differs from the reference's either the reference's own sum is noise or the exact sums with
-    the two weight vectors have different signs, i.e. the difference is the consequence of an ordered-phase decision
-    already shown to be noise-level.  Together: the result is the reference algorithm's, in exact arithmetic, with at
-    most a few noise-level decisions fallen the other way."""
-    M64 = M.astype(np.float64)
-    mag = np.abs(M64).sum(axis=1)
-    for r in range(len(orders)):
-        _noise_level_decisions(M, orders[r], ref_n[r], got_n[r])
-        if got_d is None:
-            continue
-        s_got = M64 @ np.where(got_n[r], -1.0, 1.0)
-        s_ref = M64 @ np.where(ref_n[r], -1.0, 1.0)
-        assert np.all((got_d[r] == (s_got < 0)) | (np.abs(s_got) <= 2e-6 * mag)), r
-        for i in np.nonzero(got_d[r] != ref_d[r])[0]:
-            assert abs(s_ref[i]) <= 2e-6 * mag[i] or (s_got[i] < 0) != (s_ref[i] < 0), (r, i, s_ref[i], s_got[i])
-
-
 @pytest.mark.parametrize("tag,diffuse,knn", [("n_k0", False, -1), ("d_k0", True, -1), ("n_k20", False, 20),
                                              ("d_k20", True, 20)])
 def test_xie_ordered_propagation(dev, tag, diffuse, knn):
+    """Every one of the 3 x 1000 sign decisions is the reference's (GX), ordered and diffuse phase, with and without the
+    kNN mask.  (Rounds 1-3 allowed 2 noise-level exceptions - the kernel sums a row in fp64, the reference in fp32 - and
+    proved each one to be noise; round 4 measured how many are used: none, profiles/r04_sign_slack.txt.  The reference's own
+    fp32 order - torch's CPU cascade sum, restated exactly in tools/torch_cpu_sum_order.py - was not adopted: the
+    reference's interaction matrix itself differs from any IEEE op-by-op evaluation in 10 % of its entries by an ulp, so
+    no summation order makes the row sums the reference's bits.)"""
     g = load_golden("GX_xie")
     pc = t(g["pc"]).to(dev)
     res = fu.xie_propagation_points_in_order(pc, 0.1, g["orders"], diffuse=diffuse, knn_mask=knn, C=3)
     assert res.dtype == torch.bool and res.shape == (3, 1000)
-    got, ref = res.cpu().numpy(), g[f"flip_{tag}"]
-    assert int((got != ref).sum()) <= 2
-    # sign decisions are bit-exact except where the reference's own fp32 row sum is rounding noise around zero (the
-    # kernel sums the row in fp64): every differing decision - of the ordered phase and, for the diffuse variants, of
-    # the final matrix product too - is shown to be exactly such a case or the consequence of one
-    M = fu.xie_intersaction(pc, pc, 0.1, knn, 3).cpu().numpy()
-    ntag = tag.replace("d_", "n_")
-    got_n = got if not diffuse else fu.xie_propagation_points_in_order(pc, 0.1, g["orders"], diffuse=False, knn_mask=knn,
-                                                                       C=3).cpu().numpy()
-    _consistent_with_the_reference(M, g["orders"], g[f"flip_{ntag}"], got_n, ref if diffuse else None,
-                                   got if diffuse else None)
+    assert np.array_equal(res.cpu().numpy(), g[f"flip_{tag}"])
     assert torch.equal(pc, t(g["pc"]).to(dev))                          # input untouched
 
 
 @pytest.mark.parametrize("tag,times,diffuse", [("t1_n", 1, False), ("t5_n", 5, False), ("t5_d", 5, True)])
 def test_xie_bfstree_propagation_with_vote(dev, tag, times, diffuse):
     """field_utils.xie_propagation_points_onbfstree (field_utils.py:657-710): routes, per-route flips, the vote
-    (the reference's MIQP solved by enumeration) and the final flips against GX2.  Per-route decisions may differ from
-    the reference's only as the noise argument above allows (checked for every route, ordered and diffuse phase)."""
+    (the reference's MIQP solved by enumeration), the final flips and normals against GX2 - all exactly the reference's
+    (measured in round 4: no decision differs, profiles/r04_sign_slack.txt; the earlier tests allowed 2 per route)."""
     g = load_golden("GX2_xie_bfstree")
     pts = t(g["pc"]).clone().to(dev)
     res = fu.xie_propagation_points_onbfstree(pts, 0.1, diffuse=diffuse, starting_point=0, k=10, treshold=0.1,
                                               times=times, knn_mask=-1, C=3)
     tr = fu.last_trace("bfstree")
     assert np.array_equal(tr["orders"], g[f"orders_{tag}"])
-    assert int((tr["flips"] != g[f"flips_{tag}"]).sum()) <= 2 * times
-    pc0 = t(g["pc"]).to(dev)
-    M = fu.xie_intersaction(pc0, pc0, 0.1, -1, 3).cpu().numpy()
-    ntag = tag.replace("_d", "_n")
-    assert np.array_equal(g[f"orders_{ntag}"], g[f"orders_{tag}"])
-    got_n = tr["flips"] if not diffuse else fu.xie_propagation_points_in_order(pc0, 0.1, tr["orders"], diffuse=False,
-                                                                               knn_mask=-1, C=3).cpu().numpy()
-    _consistent_with_the_reference(M, tr["orders"], g[f"flips_{ntag}"], got_n, g[f"flips_{tag}"] if diffuse else None,
-                                   tr["flips"] if diffuse else None)
+    assert np.array_equal(tr["flips"], g[f"flips_{tag}"])
     assert np.array_equal(tr["status"], g[f"status_{tag}"])
-    got = res.cpu().numpy()
-    assert int((got != g[f"result_{tag}"]).sum()) <= 2
-    same = got == g[f"result_{tag}"]
-    assert np.array_equal(pts.cpu().numpy()[same, 3:], g[f"normals_{tag}"][same])
+    assert np.array_equal(res.cpu().numpy(), g[f"result_{tag}"])
+    assert np.array_equal(pts.cpu().numpy()[:, 3:], g[f"normals_{tag}"])
     assert np.array_equal(pts.cpu().numpy()[:, :3], g["pc"][:, :3])
 
 
@@ -208,13 +159,18 @@ def test_xie_order_kernel_is_its_specification_bit_for_bit(dev, n):
     x = torch.randn(n, 6, generator=gen)
     pc = torch.cat([x[:, :3], torch.nn.functional.normalize(x[:, 3:], dim=1)], 1).to(dev)
     M = fu.xie_intersaction(pc, pc, 0.1, -1, 3).contiguous()
-    orders = np.stack([np.random.default_rng(s).permutation(n) for s in (1, 2)]).astype(np.int64)
+    # two permutations and one row that is NOT one (indices drawn with replacement: some points visited twice, some never -
+    # the reference starts from interactions = zeros, so the unvisited entries must read 0 whatever the buffers held;
+    # round-3 advisor finding: the register form left them uninitialised)
+    orders = np.stack([np.random.default_rng(s).permutation(n) for s in (1, 2)] +
+                      [np.random.default_rng(3).integers(0, n, n)]).astype(np.int64)
+    assert len(np.unique(orders[2])) < n
     order_t = t(orders).to(dev)
-    weights = torch.full((2, n), 7.0, dtype=torch.float32, device=dev)
-    inter = torch.full((2, n), 7.0, dtype=torch.float32, device=dev)
-    assert lib.dnp_xie_order_f32(_lib.ptr(M), n, _lib.ptr(order_t), 2, _lib.ptr(weights), _lib.ptr(inter), _lib.current_stream()) == 0
+    weights = torch.full((3, n), 7.0, dtype=torch.float32, device=dev)
+    inter = torch.full((3, n), 7.0, dtype=torch.float32, device=dev)
+    assert lib.dnp_xie_order_f32(_lib.ptr(M), n, _lib.ptr(order_t), 3, _lib.ptr(weights), _lib.ptr(inter), _lib.current_stream()) == 0
     Mh = M.cpu().numpy()
-    for r in range(2):
+    for r in range(3):
         want_i, want_w = _order_kernel_spec(Mh, orders[r])
         assert np.array_equal(inter[r].cpu().numpy(), want_i)
         assert np.array_equal(weights[r].cpu().numpy(), want_w)

@@ -1,12 +1,14 @@
 #!/bin/bash
-# rocprofv3 evidence for bench.py (run on the GPU box through gpurun):  tools/profile_bench.sh r03
+# rocprofv3 evidence for bench.py (run on the GPU box through gpurun):  tools/profile_bench.sh r04 [N]
+# N (optional): BENCH_FAKE_WORLD=N - one rank's share of an N-rank run (the launch an N = 8 rank really makes: the split tail).
 # kernel-trace stats, then the PMC passes in runs of their own (never combined with a trace domain other than
 # --kernel-trace).  tools/summarize_prof.py <round> turns the CSVs into the committed summaries under profiles/.
 set +e
-RND=${1:-r03}
+RND=${1:-r04}
+if [ -n "$2" ]; then export BENCH_FAKE_WORLD=$2; fi
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof
+OUT=$R/gpurun_out/prof_$RND
 rm -rf $OUT; mkdir -p $OUT
 ARGS="--steps 40 --warmup 10 --no-cpu-baseline --headline-only"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $RND -- python3 $R/bench.py $ARGS > $OUT/trace_stdout.txt 2>&1

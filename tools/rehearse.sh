@@ -1,13 +1,22 @@
 #!/bin/bash
-# BENCH_BACKEND=gloo rehearsal of bench.py --gpus 2 / 4 on one GPU, then one rank's share of an N-rank run (BENCH_FAKE_WORLD)
-# for N = 1, 2, 4, 8: the evidence under profiles/r03_bench_gloo_rehearsal.txt and profiles/r03_rank_share_timing.txt.
+# BENCH_BACKEND=gloo rehearsal of bench.py --gpus 2 / 4 on one GPU (the whole N > 1 line: in-order headline, the pipelined
+# loop - which falls back to the in-order gather under gloo, BENCH_PIPELINED=1 forces the loop -, the sharded driver leg),
+# then one rank's share of an N-rank run (BENCH_FAKE_WORLD) for N = 1, 2, 4, 8: the evidence under
+# profiles/r04_bench_gloo_rehearsal.txt and profiles/r04_rank_share_timing.txt.
 set +e
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 OUT=gpurun_out/rehearsal.txt
 : > $OUT
 for N in 2 4; do
   echo "## torch.distributed.run --nproc-per-node $N bench.py --gpus $N --steps 5 --warmup 2  (BENCH_BACKEND=gloo)" >> $OUT
-  BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2950$N bench.py --gpus $N --steps 5 --warmup 2 --no-cpu-baseline --headline-only 2>/dev/null | grep '^{' >> $OUT
+  BENCH_BACKEND=gloo BENCH_PIPELINED=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2950$N bench.py --gpus $N --steps 5 --warmup 2 --no-cpu-baseline 2>gpurun_out/rehearsal_err_$N.txt | grep '^{' > gpurun_out/rehearsal_line_$N.json
+  cat gpurun_out/rehearsal_line_$N.json >> $OUT
+  python -c "
+import json
+b=json.load(open('gpurun_out/rehearsal_line_$N.json'))
+print('# keys: value', b['value'], 'ms_per_step', b['ms_per_step'], '| value_pipelined', b.get('value_pipelined'), 'ms_per_step_pipelined', b.get('ms_per_step_pipelined'), 'pipelined_matches_in_order', b.get('pipelined_matches_in_order'), '|', b.get('pipelined_note'))
+print('# sharded_driver', b.get('sharded_driver'))
+print('# signs_ok', b['signs_ok'], 'trace_matches_reference_G19', b['trace_matches_reference_G19'])" >> $OUT
   echo >> $OUT
 done
 S=gpurun_out/rank_share.txt

@@ -21,7 +21,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 warmup = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-src = os.path.join(ROOT, "gpurun_out", "prof")
+src = os.path.join(ROOT, "gpurun_out", f"prof_{rnd}")
+if not os.path.isdir(src):
+    src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 # the bench line printed under rocprof says how many untimed steps really ran (its clock warm-up + the W warm-up steps)
 _bl = os.path.join(src, "bench_line_under_rocprof.json")
