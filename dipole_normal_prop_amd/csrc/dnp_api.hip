@@ -20,8 +20,8 @@ void clear_error() { g_err[0] = '\0'; }
 static unsigned int* g_bounds_err = nullptr;
 unsigned int* bounds_err_buffer() {
     if (!g_bounds_err) {
-        if (hipMalloc((void**)&g_bounds_err, 8 * sizeof(unsigned int)) != hipSuccess) return nullptr;
-        (void)hipMemset(g_bounds_err, 0, 8 * sizeof(unsigned int));
+        if (hipMalloc((void**)&g_bounds_err, 16 * sizeof(unsigned int)) != hipSuccess) return nullptr;
+        (void)hipMemset(g_bounds_err, 0, 16 * sizeof(unsigned int));
     }
     return g_bounds_err;
 }
@@ -45,15 +45,16 @@ int dnp_device_count(void) {
 const char* dnp_last_error(void) { return dnp::g_err; }
 
 #ifdef DNP_BOUNDS
-// check builds only: copies the eight out-of-bounds counters (pair_kernel.h kBnd*: chunk offsets, chunk boxes, tile boxes,
-// target groups, tile partials, partial slab, exchange records, source range) to the host - synchronises the device - and
-// optionally clears them.  Returns their sum, or -1 when the buffer could not be read.
-long long dnp_debug_bounds_errors(unsigned int* host_out8, int reset) {
+// check builds only: copies the counters to the host - synchronises the device - and optionally clears them: [0..7] the
+// out-of-bounds accesses by table (pair_kernel.h kBnd*: chunk offsets, chunk boxes, tile boxes, target groups, tile partials,
+// partial slab, exchange records, source range), [8] the (slab, tile) items whose rows break the two-group precondition of
+// w_part (a caller's error, not an access).  Returns the sum of [0..7], or -1 when the buffer could not be read.
+long long dnp_debug_bounds_errors(unsigned int* host_out16, int reset) {
     unsigned int* d = dnp::bounds_err_buffer();
-    unsigned int h[8] = {0};
+    unsigned int h[16] = {0};
     if (!d || hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     long long sum = 0;
-    for (int i = 0; i < 8; ++i) { sum += h[i]; if (host_out8) host_out8[i] = h[i]; }
+    for (int i = 0; i < 16; ++i) { if (i < 8) sum += h[i]; if (host_out16) host_out16[i] = h[i]; }
     if (reset) (void)hipMemset(d, 0, sizeof(h));
     return sum;
 }

@@ -141,9 +141,10 @@ struct PairBounds {
     int64_t n_partial;       // elements of partial
     int64_t n_xch_items;     // records of the exchange buffer
     int64_t n_src_rows;      // rows of src
-    unsigned int* err;       // [8] counters by table (kBnd*)
+    unsigned int* err;       // [16] counters: [0..7] out-of-bounds accesses by table (kBnd*), [8] tiles that break WPART's precondition
 };
-enum { kBndChunkOff = 0, kBndChunkBox = 1, kBndTileBox = 2, kBndTgtGroup = 3, kBndWPart = 4, kBndPartial = 5, kBndXch = 6, kBndSrc = 7 };
+enum { kBndChunkOff = 0, kBndChunkBox = 1, kBndTileBox = 2, kBndTgtGroup = 3, kBndWPart = 4, kBndPartial = 5, kBndXch = 6, kBndSrc = 7,
+       kBndGroups = 8 };
 #ifdef DNP_BOUNDS
 __device__ inline int64_t bounds_checked(int64_t idx, int64_t len, int code, unsigned int* err) {
     if (idx >= 0 && idx < len) return idx;
@@ -1053,7 +1054,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
             const int64_t t = tile_base + (int64_t)tg * (64 * KT) + k * 64 + (tid & 63);
             if (t < a.T) { const int64_t gq = a.tgt_group[DNP_BND(trow[k], n_tgt_group, kBndTgtGroup)]; bad |= (gq != g_first && gq != omax); }
         }
-        if (__any(bad) && (tid & 63) == 0 && a.bnd.err) atomicAdd(a.bnd.err + kBndWPart, 1u);
+        if (__any(bad) && (tid & 63) == 0 && a.bnd.err) atomicAdd(a.bnd.err + kBndGroups, 1u);   // the CALLER's error, not an access
     }
 #endif
     if constexpr (WPART && MODE == kField) {

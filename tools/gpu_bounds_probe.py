@@ -3,7 +3,9 @@
 subprocess): (1) the shape that faulted in round 3 - a cloud whose tile count leaves target-less wavefronts in the last
 workgroup (N = 300 + 84: 3 tiles of 128 rows, two-wavefront workgroups -> the 4th wavefront has no tile), in the plain form
 and with the split tail (four-wavefront workgroups), box tables given; (2) tools/gpu_fuzz.py for `seconds`; then prints
-the eight out-of-bounds counters of the check build as one JSON line.
+the counters of the check build as one JSON line per run: (sum of the eight out-of-bounds counters, each counter by table + the
+number of (slab, tile) items that broke w_part's two-group precondition - the fuzz passes w_part for ANY cut and ignores it
+where the cut does not allow it, so that one is expected to be nonzero there).
     DNP_LIB=tools/bin/libdnp_bounds.so python tools/gpu_bounds_probe.py [fuzz seconds = 12] [seed]"""
 import ctypes
 import json
@@ -18,13 +20,13 @@ sys.path.insert(0, ROOT)
 from dipole_normal_prop_amd import _lib  # noqa: E402
 from dipole_normal_prop_amd import field_utils as fu  # noqa: E402
 
-NAMES = ["chunk_off", "chunk_box", "tile_box", "tgt_group", "w_part", "partial", "exchange", "source_range"]
+NAMES = ["chunk_off", "chunk_box", "tile_box", "tgt_group", "w_part", "partial", "exchange", "source_range", "two_group_precondition"]
 
 
 def counters(lib, reset):
     lib.dnp_debug_bounds_errors.restype = ctypes.c_longlong
     lib.dnp_debug_bounds_errors.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    h = (ctypes.c_uint * 8)()
+    h = (ctypes.c_uint * 16)()
     total = lib.dnp_debug_bounds_errors(h, int(reset))
     return int(total), {n: int(v) for n, v in zip(NAMES, h)}
 
