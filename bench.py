@@ -107,20 +107,38 @@ def other_configs(dev, fu, util, pts_sorted, patch_ranges):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps
 
+    def timed_each(fn, reps):
+        # long calls (the per-point propagation: ~30 ms each): every repetition timed on its own, synchronised - median, min
+        # and max go on the line (round-3 verdict: 3 / 2 repetitions of this leg read 28, 35 and 47 ms in three runs)
+        for _ in range(2):
+            fn()
+            torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ts = np.array(ts)
+        return float(np.median(ts)), float(ts.min()), float(ts.max())
+
     gdir = os.path.join(ROOT, "tests", "golden")
     try:
         fandisk = torch.from_numpy(np.load(os.path.join(gdir, "G5_fandisk_allpairs.npz"))["pc"]).to(dev)
         t = timed(lambda: fu.field_grad(fandisk, fandisk), 20)
         out["config2_fandisk_allpairs"] = {"points": int(fandisk.shape[0]), "us_per_call": t * 1e6,
                                            "pairs_per_s": fandisk.shape[0] ** 2 / t}
-        ok = torch.from_numpy(np.load(os.path.join(gdir, "G8_point_propagation.npz"))["pc_full"])
-        t = timed(lambda: fu.strongest_field_propagation_points(ok.clone().to(dev), diffuse=True), 3)
-        out["config1_ok_point_propagation"] = {"points": int(ok.shape[0]), "ms": t * 1e3,
-                                               "us_per_step": t / ok.shape[0] * 1e6}
+        # config 1: the cloud is resident in HBM before the timed region (as for every leg: the copy of a HOST tensor inside
+        # the loop - torch's multi-threaded CPU clone under a CPU quota - was what made this leg read 28 ... 50 ms in round 3;
+        # the kernel itself is steady within 5 %, profiles/r04_k4_spread.txt); 12 repetitions, each timed on its own
+        ok = torch.from_numpy(np.load(os.path.join(gdir, "G8_point_propagation.npz"))["pc_full"]).to(dev)
+        med, lo, hi = timed_each(lambda: fu.strongest_field_propagation_points(ok.clone(), diffuse=True), 12)
+        out["config1_ok_point_propagation"] = {"points": int(ok.shape[0]), "ms": med, "ms_min": lo, "ms_max": hi, "repetitions": 12,
+                                               "us_per_step": med / ok.shape[0] * 1e3}
         ok64 = ok.double()
-        t = timed(lambda: fu.strongest_field_propagation_points(ok64.clone().to(dev), diffuse=True), 2)
-        out["config1_ok_point_propagation_f64"] = {"points": int(ok.shape[0]), "ms": t * 1e3,
-                                                   "us_per_step": t / ok.shape[0] * 1e6}
+        med, lo, hi = timed_each(lambda: fu.strongest_field_propagation_points(ok64.clone(), diffuse=True), 12)
+        out["config1_ok_point_propagation_f64"] = {"points": int(ok.shape[0]), "ms": med, "ms_min": lo, "ms_max": hi,
+                                                   "repetitions": 12, "us_per_step": med / ok.shape[0] * 1e3}
         g15 = np.load(os.path.join(gdir, "G15_boxunion_config3.npz"))
         cloud = torch.from_numpy(g15["pc"]).clone()
         cloud[~torch.from_numpy(g15["prefilter_sign"]), 3:] *= -1

@@ -321,6 +321,9 @@ struct MultiArgs {
     unsigned long long* slots;   // [2 parities][words per group][kMaxGroups]
     int* status;                 // [0] = 0 ok, 1 timeout
     int per_group;               // points per workgroup (multiple of 512)
+#ifdef DNP_K4_STATS              // instrumented builds only (tools/gpu_k4_spread.py): where does a step's time go, and at what clock
+    unsigned long long* stats;   // [N][4] per step, by workgroup 0: {100 MHz wall clock, shader clock counter, spins of lane 0, -};
+#endif                           // then [G][2] per workgroup: {HW_ID, XCC_ID}
 };
 
 template <typename F> struct Granule;
@@ -371,6 +374,14 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(cons
     }
     visited = ~valid;
     argmax_init<F>(am);
+#ifdef DNP_K4_STATS
+    if (tid == 0 && a.stats) {
+        unsigned h, x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(h), "=s"(x));
+        a.stats[(size_t)a.N * 4 + (size_t)g * 2] = h;
+        a.stats[(size_t)a.N * 4 + (size_t)g * 2 + 1] = x;
+    }
+#endif
     if (tid == 0) {
         abort_flag = 0;
         const F* p = a.pts + (int64_t)a.start * a.ld;
@@ -432,6 +443,9 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(cons
             Key<F> best = Key<F>::none();
             F r0 = F(0), r1 = F(0), r2 = F(0), r3 = F(0), r4 = F(0), r5 = F(0);
             bool timed_out = false;
+#ifdef DNP_K4_STATS
+            unsigned long long k4_spins = 0;
+#endif
             for (int q = lane; q < G; q += 64) {
                 unsigned long long gran[kW];
                 unsigned spins = 0;
@@ -452,6 +466,9 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(cons
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (timed_out) break;
+#ifdef DNP_K4_STATS
+                k4_spins += spins;
+#endif
                 const unsigned idx = (unsigned)(gran[0] >> 32) & kIdxMask;
                 if (idx != kIdxMask) {
                     const Key<F> c = Key<F>::make(Granule<F>::value(gran), (int)idx);
@@ -468,6 +485,14 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(cons
                     abort_flag = 1;
                 }
             }
+#ifdef DNP_K4_STATS
+            if (g == 0 && lane == 0 && a.stats) {
+                unsigned long long t_wall, t_core;
+                asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_wall), "=s"(t_core));
+                unsigned long long* q = a.stats + (size_t)step * 4;
+                q[0] = t_wall; q[1] = t_core; q[2] = k4_spins;
+            }
+#endif
             const Key<F> wbest = wave_best<F>(best);
             if (best.valid() && !best.beats(wbest) && !wbest.beats(best)) {      // exactly one lane: keys are unique per point
                 win_row[0] = r0; win_row[1] = r1; win_row[2] = r2; win_row[3] = r3; win_row[4] = r4; win_row[5] = r5;
@@ -503,6 +528,10 @@ template <> struct GreedyCap<double> { static constexpr int kMaxPPT = 8; };
 
 constexpr size_t kGreedyHeader = 256;                                         // status word (+ padding)
 constexpr size_t kGreedySlots = 2 * 2 * kMaxGroups * sizeof(unsigned long long);   // 2 parities x <= 2 words x groups
+
+#ifdef DNP_K4_STATS
+static unsigned long long* g_k4_stats = nullptr;      // set by dnp_debug_set_k4_stats: [N][4] + [groups][2] words (device)
+#endif
 
 template <typename F>
 static int run_point_greedy(F* pts, int64_t N, int64_t ld_pts, int64_t start, F eps, int diffuse, int64_t* order_out,
@@ -566,6 +595,9 @@ static int run_point_greedy(F* pts, int64_t N, int64_t ld_pts, int64_t start, F 
         // granule leaves, then all do; what a time-out in the field looks like, on demand (tests)
         if (form == 3) DNP_CHECK_HIP(hipMemsetAsync(status, 1, 1, st));
         MultiArgs<F> ma{pts, N, ld_pts, (int)start, eps, diffuse, order_out, E_out, n_out, slots, status, (int)per};
+#ifdef DNP_K4_STATS
+        ma.stats = g_k4_stats;
+#endif
         // Co-residency: the all-gather may only wait for workgroups that are on the chip.  One workgroup per CU at
         // most, and the occupancy query must confirm that a CU holds one (the check hipLaunchCooperativeKernel would
         // make; the cooperative launch itself is avoided because rocprofv3 (ROCm 7.2) crashes at exit in a process
@@ -609,6 +641,10 @@ size_t dnp_point_greedy_workspace_bytes(int64_t N, int elem_size) {
 }
 
 int dnp_point_greedy_max_points(void) { return (int)kIdxMask; }   // index field of the granule: N < 2^20
+
+#ifdef DNP_K4_STATS
+int dnp_debug_set_k4_stats(void* p) { dnp::g_k4_stats = (unsigned long long*)p; return 0; }
+#endif
 
 int dnp_point_greedy_f32(float* pts, int64_t N, int64_t ld_pts, int64_t start, float eps, int diffuse,
                          int64_t* order_out, float* E_out, int form, int max_groups, void* workspace,
