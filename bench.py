@@ -203,11 +203,18 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
+    # BENCH_ONE_RANK_RCCL=1 (one GPU, no launcher): a ONE-rank nccl group, so that the pipelined loop's asynchronous all-gather
+    # runs through RCCL itself on a single-GPU box (rehearsal of that code path; the line says "rehearsal")
+    one_rank_rccl = world == 1 and bool(os.environ.get("BENCH_ONE_RANK_RCCL"))
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    elif one_rank_rccl:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     from dipole_normal_prop_amd import field_utils as fu
     from dipole_normal_prop_amd import parallel, util
@@ -235,7 +242,8 @@ def main():
     # The headline step gathers in the launch stream's order (what the product's driver does).  At N > 1 over RCCL a second
     # timed loop overlaps the all-gather with the next step's pair kernel (BENCH_NO_PIPELINED=1 skips it; BENCH_PIPELINED=1
     # forces it on other backends / one rank, where gather_rows_async falls back to the in-order form).
-    can_pipeline = (world > 1 and backend == "nccl" and not os.environ.get("BENCH_NO_PIPELINED")) or bool(os.environ.get("BENCH_PIPELINED"))
+    can_pipeline = ((world > 1 and backend == "nccl" and not os.environ.get("BENCH_NO_PIPELINED")) or bool(os.environ.get("BENCH_PIPELINED"))
+                    or one_rank_rccl)
     pending = []
     overlap_state = {"on": False, "async_seen": False}
 
@@ -266,7 +274,7 @@ def main():
             # kernel (the steps are independent batches); two in flight at most: the gather of step i - 2 is consumed before
             # step i issues its own
             try:
-                W, work = parallel.gather_rows_async(W, bounds)
+                W, work = parallel.gather_rows_async(W, bounds, force=one_rank_rccl)
             except Exception as exc:           # never lose a scaling run to the overlap: fall back to the in-order gather
                 print(f"bench: asynchronous all-gather unavailable ({exc!r}); continuing with the in-order form", file=sys.stderr)
                 overlap_state["on"] = False
@@ -495,6 +503,8 @@ def main():
             out["sharded_driver"] = sharded_driver
         if fake > 1 and world == 1:
             out["fake_world"] = fake          # NOT a measurement of `fake` GPUs: one rank's share on one GPU
+        if one_rank_rccl:
+            out["rehearsal"] = "ONE-rank nccl group on one GPU: exercises the asynchronous RCCL all-gather of the pipelined loop, not a scaling number"
         if world > 1 and backend != "nccl":
             out["rehearsal"] = (f"{backend} collectives; ranks may share a GPU (device_count "
                                 f"{torch.cuda.device_count()}): a functional rehearsal of the N>1 path, not a scaling number")
@@ -508,6 +518,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
+        dist.destroy_process_group()
+    elif one_rank_rccl:
         dist.destroy_process_group()
 
 

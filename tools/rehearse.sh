@@ -27,3 +27,9 @@ import json,sys
 b=json.loads(sys.stdin.read()); r=b['roofline']; print($N, round(b['ms_per_step'],4), round(r['launch_ms'],4), round(r['launch_ms_median'],4), round(r['launch_ms_min'],4), r['source_split'], b['step_parts']['interactions_kernel_ms'])" >> $S
 done
 cat $S
+# the asynchronous all-gather of the pipelined loop through RCCL itself, with the one rank a one-GPU box allows
+echo "## BENCH_ONE_RANK_RCCL=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --headline-only  (one-rank nccl group)" >> $OUT
+BENCH_ONE_RANK_RCCL=1 timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --headline-only 2>gpurun_out/rehearsal_err_rccl1.txt | grep '^{' | python -c "
+import json,sys
+b=json.loads(sys.stdin.read())
+print('# keys: value', b['value'], 'ms_per_step', b['ms_per_step'], '| value_pipelined', b.get('value_pipelined'), 'ms_per_step_pipelined', b.get('ms_per_step_pipelined'), 'pipelined_matches_in_order', b.get('pipelined_matches_in_order'), '|', b.get('pipelined_note'), '|', b.get('rehearsal'))" >> $OUT
