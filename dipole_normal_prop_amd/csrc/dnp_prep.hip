@@ -143,6 +143,17 @@ __device__ __forceinline__ void wave_argmax(double& bv, int& bj) {
     for (int off = 16; off <= 32; off <<= 1) take_better(bv, bj, __shfl_xor(bv, off, 64), __shfl_xor(bj, off, 64));
 }
 
+// the wave's maximum of bv in every lane (values only: three instructions per round instead of ten)
+__device__ __forceinline__ double wave_max_f64(double v) {
+    v = __builtin_fmax(v, dpp_f64<0xB1>(v));
+    v = __builtin_fmax(v, dpp_f64<0x4E>(v));
+    v = __builtin_fmax(v, dpp_f64<0x141>(v));
+    v = __builtin_fmax(v, dpp_f64<0x140>(v));
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) v = __builtin_fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
 template <int EPL>
 __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restrict__ W, int P,
                                                           const int64_t* __restrict__ start_ptr,
@@ -161,6 +172,19 @@ __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restri
     for (int e = 0; e < EPL; ++e) {
         inter[e] = 0.0;
         if (e * 64 + lane >= P) visited |= 1ull << e;
+    }
+#ifndef DNP_PG_PRETOUCH   // 0: A/B builds without the pass over W in front of the loop (tools/gpu_pg_time.py)
+#define DNP_PG_PRETOUCH 1
+#endif
+    if (DNP_PG_PRETOUCH && (int64_t)P * P * 8 <= (2 << 20)) {
+        // W was written by other CUs a moment ago: a row load of the loop is served by the memory-side cache (~230 ns) until this
+        // XCD's L2 has the line (~85 ns).  One pass over the matrix puts all of it there.
+        const double2* w2 = reinterpret_cast<const double2*>(W);
+        const int64_t n2 = (int64_t)P * P / 2;
+        double t = 0.0;
+#pragma unroll 16
+        for (int64_t i = lane; i < n2; i += 64) { const double2 v = w2[i]; t += v.x + v.y; }
+        if (t == 1.2345e300) order_s[0] = -1;            // never true: keeps the loads
     }
     double s = 1.0;                                       // the start patch is not flipped
     for (int step = 0; step < P; ++step) {
@@ -189,8 +213,26 @@ __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restri
             if (a != a) a = __builtin_huge_val();
             if (!((visited >> e) & 1ull) && a > bv) { bv = a; bj = e * 64 + lane; }
         }
-        wave_argmax(bv, bj);
-        cur = __builtin_amdgcn_readfirstlane(bj);        // wave-uniform
+#ifndef DNP_PG_FAST_ARGMAX   // 0: A/B builds that keep the (value, index) butterfly on every step
+#define DNP_PG_FAST_ARGMAX 1
+#endif
+        // The step is one dependent chain, so the argmax's length is paid 255 times: first the wave's maximum VALUE alone
+        // (no index travels, no tie rule: 3 instructions per butterfly round), then a ballot of the lanes that hold it.  One
+        // such lane (what happens but for exact fp64 ties): its candidate is the winner.  Several: the full (value, index)
+        // butterfly with the first-in-patch-order rule - the same result either way.
+        bool decided = false;
+        if (DNP_PG_FAST_ARGMAX) {
+            const double m = wave_max_f64(bv);           // no NaN here: a NaN |I| was made +inf above, "none" is -1
+            const unsigned long long tied = __ballot(bv == m && bj != 0x7fffffff);
+            if (__builtin_popcountll(tied) == 1) {
+                cur = __builtin_amdgcn_readlane(bj, (int)__builtin_ctzll(tied));
+                decided = true;
+            }
+        }
+        if (!decided) {
+            wave_argmax(bv, bj);
+            cur = __builtin_amdgcn_readfirstlane(bj);    // wave-uniform
+        }
         // the winner's signed interaction lives in lane cur & 63, entry cur >> 6
         double mine = 0.0;
 #pragma unroll
