@@ -2,7 +2,7 @@
 (BASELINE config 5): where the time of a reference_field call goes."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import sphere_cloud, fibonacci_patches
+from tools.workloads import sphere_cloud, fibonacci_patches
 from dipole_normal_prop_amd import field_utils as fu, util
 dev = torch.device("cuda:0")
 pc = sphere_cloud(); patches = fibonacci_patches(pc)

@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from dipole_normal_prop_amd import field_utils as fu
-from bench import sphere_cloud, fibonacci_patches
+from tools.workloads import sphere_cloud, fibonacci_patches
 dev = torch.device("cuda:0")
 pc = sphere_cloud()
 patches = [p.to(dev) for p in fibonacci_patches(pc)]

@@ -5,7 +5,7 @@ import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import fibonacci_patches, sphere_cloud  # noqa: E402
+from tools.workloads import fibonacci_patches, sphere_cloud  # noqa: E402
 from dipole_normal_prop_amd import field_utils as fu, util  # noqa: E402
 dev = torch.device("cuda:0")
 pc = sphere_cloud()

@@ -4,7 +4,7 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dipole_normal_prop_amd import field_utils as fu, util
-from bench import sphere_cloud, fibonacci_patches
+from tools.workloads import sphere_cloud, fibonacci_patches
 dev = torch.device("cuda:0")
 pc = sphere_cloud(); patches = fibonacci_patches(pc)
 off, idx, _ = util.patch_csr(patches, dev)
