@@ -1,0 +1,34 @@
+"""The register / LDS budget of the hot kernels, from a compile-only pass (hipcc cross-compiles gfx950 without a GPU;
+tools/isa_resources.py).  The scalar-unit pair kernel runs at 8 wavefronts per SIMD because it stays at <= 64 VGPRs, and its
+tabled forms - the bench's kernel and the exchange-tail kernel - carry no LDS at all (round 3: merely carrying 9 KB cost
+2.4 %); hipcc's allocation for this kernel is fragile (codegen caveat: a side effect in the prologue
+moved it from 61 to 72-78 VGPRs), so an edit that breaks the budget should fail here, not be found in a profile."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not found")
+def test_tabled_pair_kernels_keep_their_register_and_lds_budget():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_resources.py"), "dnp_patch.hip"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = {}
+    for line in out.stdout.splitlines():
+        m = re.match(r"(\S.*?)\s+VGPR\s+(\d+) SGPR\s+(\d+) LDS\s+(\d+) occ (\d+) scratch (\d+)", line)
+        if m:
+            rows[m.group(1).strip()] = tuple(int(x) for x in m.groups()[1:])
+    tabled = {k: v for k, v in rows.items() if k.startswith("pair_kernel_scalar<float, float, 0, 2, 0, true, true, true")}
+    assert len(tabled) == 4, sorted(rows)                      # plain / exchange-tail form, each with and without the partials
+    for name, (vgpr, sgpr, lds, occ, scratch) in tabled.items():
+        assert vgpr <= 64 and occ == 8, (name, vgpr, occ)      # 8 wavefronts per SIMD
+        assert sgpr <= 80, (name, sgpr)                        # above 80 the hardware admits 7 (MI355X_MICROARCH.md)
+        assert lds == 0 and scratch == 0, (name, lds, scratch)
+    for name, (vgpr, sgpr, lds, occ, scratch) in rows.items():
+        if name.startswith("pair_kernel_scalar"):
+            assert vgpr <= 64 and scratch == 0, (name, vgpr, scratch)
