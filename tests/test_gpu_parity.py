@@ -512,6 +512,41 @@ def test_source_split_does_not_change_a_bit(dev):
         assert rel_rowwise(b[k].cpu()[others], ref) < TOL
 
 
+def test_split_tail_on_two_streams_and_two_threads_at_once(dev):
+    """The exchange buffer serves ONE stream at a time; field_utils keeps one per (thread, device, stream).  Two Python threads,
+    each on a stream of its own, run split-tail launches of different sizes at the same time (the reference calls the drivers
+    from threads, util.py:187-196): every result equals the plain launch's, bit for bit."""
+    import threading
+    from tools.workloads import headline_workload
+    pc, patches, _ = headline_workload()
+    off, idx, sizes = util.patch_csr([p.to(dev) for p in patches], dev)
+    swork = pc.to(dev)[idx].contiguous()
+    P = len(sizes)
+    point_patch = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
+    boxes, tiles = fu._patch_boxes(swork, off, None), fu._TileTables(swork, sizes)
+    want = {(lo, hi): fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, None, 1)
+            for lo, hi in ((0, 12), (100, 124))}
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(lo, hi, k):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for _ in range(6):
+                    got = fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, None, -k)
+                    if not torch.equal(got, want[(lo, hi)]):
+                        errors.append((lo, hi, k))
+            st.synchronize()
+        except Exception as exc:                     # pragma: no cover - reported below
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=a) for a in ((0, 12, 3), (100, 124, 5))]
+    [t_.start() for t_ in threads]
+    [t_.join() for t_ in threads]
+    assert not errors, errors
+
+
 @pytest.mark.parametrize("eps", [1e-40, 1e-33, 1e-30, 3e-12])
 def test_far_chain_is_safe_for_tiny_eps(dev, eps):
     """Round-2 advisor finding: with a denormal / tiny eps the far-field threshold (eps / 4e-3)^(2/3) admitted pairs whose
