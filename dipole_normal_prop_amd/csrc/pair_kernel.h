@@ -404,33 +404,40 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
         for (int c = 0; c < NC; ++c) acc[k][c] = 0.0;
 
     // ---- staging helpers -------------------------------------------------------------------
-    F g0, g1, g2, g3, g4, g5;
-    auto load_row = [&](int64_t s) {
+    // (a staged row travels BY VALUE: with six scalars captured by reference hipcc kept two of them in scratch memory - a
+    // store -> load round trip through the private segment in every workgroup's prologue and once per tile, and a kernel
+    // that needs a private segment at all; found in round 4 by tools/isa_resources.py's scratch column)
+    struct Staged { Vec4<F> lo, hi; };
+    auto load_row = [&](int64_t s) -> Staged {
+        Staged r;
+        r.lo = Vec4<F>{M::kFar, M::kFar, M::kFar, F(0)};      // padding row: infinitely far, zero dipole -> contributes exactly 0
+        r.hi = Vec4<F>{F(0), F(0), F(0), F(0)};
         if (s < s_end) {
             const int64_t row = a.src_idx ? a.src_idx[s] : s;
             const F* p = a.src + row * a.ld_src;
-            g0 = p[0]; g1 = p[1]; g2 = p[2]; g3 = p[3]; g4 = p[4]; g5 = p[5];
-        } else {  // padding row: infinitely far, zero dipole -> contributes exactly 0
-            g0 = g1 = g2 = M::kFar; g3 = g4 = g5 = F(0);
+            r.lo = Vec4<F>{p[0], p[1], p[2], p[3]};
+            r.hi = Vec4<F>{p[4], p[5], F(0), F(0)};
         }
+        return r;
     };
-    auto store_row = [&](int buf) {
-        lds[buf][tid][0] = Vec4<F>{g0, g1, g2, g3};
-        lds[buf][tid][1] = Vec4<F>{g4, g5, F(0), F(0)};
+    auto store_row = [&](int buf, const Staged& r) {
+        lds[buf][tid][0] = r.lo;
+        lds[buf][tid][1] = r.hi;
     };
+    Staged staged;
 
     const int64_t n_src = s_end - s_begin;
     const int64_t n_tiles = (n_src + kBlock - 1) / kBlock;
     if (n_tiles > 0) {
-        load_row(s_begin + tid);
-        store_row(0);
+        staged = load_row(s_begin + tid);
+        store_row(0, staged);
     }
     __syncthreads();
 
     for (int64_t it = 0; it < n_tiles; ++it) {
         const int buf = (int)(it & 1);
         const int64_t tile_s = s_begin + it * kBlock;
-        if (it + 1 < n_tiles) load_row(tile_s + kBlock + tid);   // in flight during the compute below
+        if (it + 1 < n_tiles) staged = load_row(tile_s + kBlock + tid);   // in flight during the compute below
         int n_here = (int)((s_end - tile_s) < kBlock ? (s_end - tile_s) : kBlock);
         n_here = (n_here + 3) & ~3;                                // rows past s_end are padding rows (kUnroll | 4)
 
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(kBlock) void pair_kernel(const PairArgs<F, PT> a) {
                                               : (double)(P[0][k] + P[1][k]);
             }
         }
-        if (it + 1 < n_tiles) store_row(buf ^ 1);
+        if (it + 1 < n_tiles) store_row(buf ^ 1, staged);
         __syncthreads();
     }
 

@@ -32,3 +32,24 @@ def test_tabled_pair_kernels_keep_their_register_and_lds_budget():
     for name, (vgpr, sgpr, lds, occ, scratch) in rows.items():
         if name.startswith("pair_kernel_scalar"):
             assert vgpr <= 64 and scratch == 0, (name, vgpr, scratch)
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not found")
+def test_no_pair_kernel_needs_a_private_segment():
+    """Round 4 found every LDS-staged pair kernel with 12 bytes of scratch per lane (two of six staged scalars captured by
+    reference went through the private segment: a store -> load round trip in each workgroup's prologue); the staged row
+    travels by value now.  No pair kernel of the generic entry points may need scratch, and the small-call kernel
+    (KT = 1, fp32) keeps its 8 wavefronts per SIMD."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_resources.py"), "dnp_field.hip"], capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    seen = 0
+    for line in out.stdout.splitlines():
+        m = re.match(r"(pair_kernel\S*<.*?>)\s+VGPR\s+(\d+) SGPR\s+(\d+) LDS\s+(\d+) occ (\d+) scratch (\d+)", line)
+        if not m:
+            continue
+        seen += 1
+        assert int(m.group(6)) == 0, line
+        if m.group(1).startswith("pair_kernel<float, double, 0, 1,") or m.group(1).startswith("pair_kernel<float, double, 1, 1,"):
+            assert int(m.group(5)) == 8, line
+    assert seen >= 24
