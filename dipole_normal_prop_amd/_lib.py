@@ -10,6 +10,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DNP_LIB", os.path.join(_HERE, "libdnp.so"))
 
+ABI_VERSION = 400          # DNP_VERSION of include/dnp.h this binding matches (argument lists changed in 0.4.0)
+
 _c_i64 = ctypes.c_int64
 _c_p = ctypes.c_void_p
 _c_sz = ctypes.c_size_t
@@ -105,14 +107,27 @@ def load():
                 from . import build as _build
                 _build.build(verbose=False)
             except Exception as exc:
-                raise DnpError(f"{LIB_PATH} not found and building it failed ({exc}); run "
-                               "`python -m dipole_normal_prop_amd.build` - there is no CPU fallback for the "
-                               "field kernels") from exc
+                if not os.path.exists(LIB_PATH):
+                    raise DnpError(f"{LIB_PATH} not found and building it failed ({exc}); run "
+                                   "`python -m dipole_normal_prop_amd.build` - there is no CPU fallback for the "
+                                   "field kernels") from exc
+                # a library exists but a source looks newer and the rebuild failed (no hipcc on this box, a read-only tree):
+                # say so and use the library that is there - its dnp_version() is checked against the header below
+                import warnings
+                warnings.warn(f"libdnp.so is older than its sources and rebuilding it failed ({exc}); using the existing library")
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as exc:               # an older library than this binding: never call it with a shifted ABI
+                raise DnpError(f"{LIB_PATH} does not export {name}: it was built from other sources than this package; "
+                               "run `python -m dipole_normal_prop_amd.build --force`") from exc
             fn.restype = res
             fn.argtypes = args
+        lib.dnp_version.restype = ctypes.c_int
+        if lib.dnp_version() != ABI_VERSION:
+            raise DnpError(f"{LIB_PATH} reports ABI version {lib.dnp_version()}, this binding is written for {ABI_VERSION}; "
+                           "run `python -m dipole_normal_prop_amd.build --force`")
         _lib = lib
     return _lib
 
