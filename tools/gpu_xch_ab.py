@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Round 4: the split tail through the exchange buffer (pair_kernel.h XCH: no LDS, no barrier, last arriver adds the run
-terms in run order) against the plain launch and against round 3's LDS form of the tail, on the bench workload's first K
-patches (K = a rank's share of 256 / K ranks ... the whole launch).  Same process, interleaved, medians of 30 launches;
+terms in run order) against the plain launch, on the bench workload's first K patches (K = a rank's share of 256 / K ranks
+... the whole launch).  (While round 3's LDS forms of the split still existed this tool also timed them: the lds-3 / lds-all
+columns of profiles/r04_xch_ab.txt.)  Same process, interleaved, medians of 30 launches;
 every variant's slabs and interaction partials are compared bit for bit with the plain launch's.
     python tools/gpu_xch_ab.py            (on the GPU box)"""
 import ctypes
@@ -55,14 +56,12 @@ def timed(fn, reps=30):
 
 
 ks = [int(x) for x in os.environ.get("XCH_KS", "1,2,3,4,6,8,12,16").split(",")]
-print("# ms per launch (median of 30): plain = source_split 1; lds-3 = round 3's tail; x-k = the last k patches split through the exchange buffer")
+print("# ms per launch (median of 30): plain = source_split 1; x-k = the last k patches split through the exchange buffer")
 for K in [int(x) for x in os.environ.get("XCH_K", "4,8,16,32,48,64,128,256").split(",")]:
     launch(K, 1, False)
     torch.cuda.synchronize()
     ref, wref = dE[:K].clone(), wp[:K].clone()
     line = f"K={K:3d}: plain {timed(lambda: launch(K, 1, False)):.4f}"
-    if K > 3:
-        line += f"  lds-3 {timed(lambda: launch(K, -3, False)):.4f}  lds-all {timed(lambda: launch(K, 4, False)):.4f}"
     for k in ks + [K]:
         if k > K or (k == K and K in ks):
             continue
