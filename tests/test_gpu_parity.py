@@ -480,6 +480,17 @@ def test_source_split_does_not_change_a_bit(dev):
     xch = fu._exchange(1, dev)
     item = int(_lib.load().dnp_patch_exchange_bytes(N, 1)) // tiles.n_tiles
     assert int(xch[: 24 * tiles.n_tiles * item].view(-1, item)[:, :128].sum().item()) == 0
+    # the raw C ABI with a caller's own buffer: dirty memory, zeroed by dnp_exchange_init, then two launches of different sizes
+    lib = _lib.load()
+    nb = int(lib.dnp_patch_exchange_bytes(N, 5))
+    own = torch.full((nb,), 0xa5, dtype=torch.uint8, device=dev)
+    assert lib.dnp_exchange_init(_lib.ptr(own), nb, _lib.current_stream()) == 0
+    for k in (5, 2):
+        dEr = torch.full((24, N, 3), float("nan"), dtype=torch.float32, device=dev)
+        rc = lib.dnp_patch_fields_tiled_f32(_lib.ptr(swork), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch), _lib.ptr(boxes),
+                                            _lib.ptr(tiles.boxes), 40, 64, 1e-5, _lib.ptr(dEr), None, -k, _lib.ptr(own), nb,
+                                            _lib.current_stream())
+        assert rc == 0 and torch.equal(dEr, res[1][0]), k
     # a split launch without the buffer is refused, not run wrong
     dE = torch.empty((24, N, 3), dtype=torch.float32, device=dev)
     rc = _lib.load().dnp_patch_fields_tiled_f32(_lib.ptr(swork), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch), _lib.ptr(boxes),
