@@ -322,7 +322,7 @@ struct MultiArgs {
     int* status;                 // [0] = 0 ok, 1 timeout
     int per_group;               // points per workgroup (multiple of 512)
 #ifdef DNP_K4_STATS              // instrumented builds only (tools/gpu_k4_spread.py): where does a step's time go, and at what clock
-    unsigned long long* stats;   // [N][4] per step, by workgroup 0: {100 MHz wall clock, shader clock counter, spins of lane 0, -};
+    unsigned long long* stats;   // [N][4] per step, by workgroup 0: {wall clock at the step's end (100 MHz), shader clock counter, spins of its slowest polling lane, wall clock when it had published};
 #endif                           // then [G][2] per workgroup: {HW_ID, XCC_ID}
 };
 
@@ -444,7 +444,8 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(cons
             F r0 = F(0), r1 = F(0), r2 = F(0), r3 = F(0), r4 = F(0), r5 = F(0);
             bool timed_out = false;
 #ifdef DNP_K4_STATS
-            unsigned long long k4_spins = 0;
+            unsigned long long k4_spins = 0, k4_t_pub = 0;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(k4_t_pub));     // published: the wait for the others starts
 #endif
             for (int q = lane; q < G; q += 64) {
                 unsigned long long gran[kW];
@@ -486,11 +487,16 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(cons
                 }
             }
 #ifdef DNP_K4_STATS
-            if (g == 0 && lane == 0 && a.stats) {
-                unsigned long long t_wall, t_core;
-                asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_wall), "=s"(t_core));
-                unsigned long long* q = a.stats + (size_t)step * 4;
-                q[0] = t_wall; q[1] = t_core; q[2] = k4_spins;
+            {
+                unsigned long long smax = k4_spins;          // the slowest lane's spins: how long this workgroup waited for the others
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(smax, off, 64); smax = o > smax ? o : smax; }
+                if (g == 0 && lane == 0 && a.stats) {
+                    unsigned long long t_wall, t_core;
+                    asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_wall), "=s"(t_core));
+                    unsigned long long* q = a.stats + (size_t)step * 4;
+                    q[0] = t_wall; q[1] = t_core; q[2] = smax; q[3] = k4_t_pub;
+                }
             }
 #endif
             const Key<F> wbest = wave_best<F>(best);

@@ -8,8 +8,9 @@ Part 1 - the product library: the call timed 14 times in three regimes of what r
     chained back to back, each call the previous one's predecessor
 Part 2 - a -DDNP_K4_STATS build (tools/bin/libdnp_k4stats.so): workgroup 0 stamps every step with the 100 MHz wall clock AND
 the shader clock counter (their ratio IS the clock the kernel ran at) and its spin count; every workgroup leaves the XCD
-and CU it ran on.  Printed per call: total ms, effective shader clock, step-time percentiles in ns, spins per poll, the
-XCDs of the 20 workgroups.
+and CU it ran on.  Printed per call: total ms, effective shader clock, step-time percentiles in ns, spins of the slowest polling lane, the
+XCDs of the 20 workgroups, and the step split into workgroup 0's own work (field update + local argmax, up to the publish) and the
+rest (all-gather of the 20 granules, the winner's row, the wave argmax).
     python tools/gpu_k4_spread.py            (on the GPU box; output -> profiles/r04_k4_spread.txt)"""
 import ctypes
 import os
@@ -92,7 +93,7 @@ def main():
     stats = torch.zeros(N * 4 + 256 * 2, dtype=torch.int64, device=dev)
     slib.dnp_debug_set_k4_stats(_lib.ptr(stats))
     print("# part 2: -DDNP_K4_STATS build, per call: ms | effective shader clock GHz (shader-clock ticks / wall time, whole call and by "
-          "quarter of the steps) | step ns p10 p50 p90 p99 max | lane-0 spins per step mean | XCD of each workgroup")
+          "quarter of the steps) | step ns p10 p50 p90 p99 max | slowest lane's spins per step, mean | XCD of each workgroup | split of a step")
     for regime in ("cold", "warm", "warm", "chained", "chained", "chained"):
         if regime == "cold":
             time.sleep(1.5)
@@ -103,14 +104,18 @@ def main():
         st = stats.cpu().numpy().astype(np.uint64)
         per = st[: (N - 1) * 4].reshape(N - 1, 4)
         wall, core, spins = per[:, 0].astype(np.float64), per[:, 1].astype(np.float64), per[:, 2].astype(np.float64)
+        pub = per[:, 3].astype(np.float64)
         step_ns = np.diff(wall) * 10.0
+        own_ns = (pub[1:] - wall[:-1]) * 10.0        # end of the previous step -> this step's granule published (field update + local argmax)
+        wait_ns = (wall[1:] - pub[1:]) * 10.0        # published -> all granules polled, winner's row fetched, wave argmax done
         ghz = (core[-1] - core[0]) / ((wall[-1] - wall[0]) * 10.0)
         q = len(wall) // 4
         ghz_q = [(core[(i + 1) * q - 1] - core[i * q]) / ((wall[(i + 1) * q - 1] - wall[i * q]) * 10.0) for i in range(4)]
         grp = st[N * 4: N * 4 + 40].reshape(20, 2)
         print(f"{regime:8s} {ms:6.2f} ms | {ghz:.2f} GHz ({' '.join(f'{g:.2f}' for g in ghz_q)}) | "
               f"{np.percentile(step_ns, 10):.0f} {np.percentile(step_ns, 50):.0f} {np.percentile(step_ns, 90):.0f} "
-              f"{np.percentile(step_ns, 99):.0f} {step_ns.max():.0f} | {spins.mean():.1f} | {''.join(str(int(x)) for x in grp[:, 1])}", flush=True)
+              f"{np.percentile(step_ns, 99):.0f} {step_ns.max():.0f} | {spins.mean():.1f} | {''.join(str(int(x)) for x in grp[:, 1])}"
+              f" | own work p50 {np.percentile(own_ns, 50):.0f} ns, gather + row + argmax p50 {np.percentile(wait_ns, 50):.0f} ns", flush=True)
 
 
 if __name__ == "__main__":
