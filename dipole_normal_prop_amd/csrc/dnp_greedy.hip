@@ -119,20 +119,49 @@ template <int CTRL> __device__ __forceinline__ Key<double> key_dpp(const Key<dou
     return Key<double>{dpp_u64<CTRL>(k.a), dpp_u32<CTRL>(k.lo)};
 }
 
-// the wave's best key in every lane: four rounds on DPP (quad_perm lane^1, lane^2; row_half_mirror; row_mirror - all
-// register to register), two rounds across the 16-lane rows through ds_bpermute
+// the wave's best key as a wave-uniform value: four butterfly rounds on DPP (quad_perm lane^1, lane^2; row_half_mirror;
+// row_mirror) leave every 16-lane row's best in all of its lanes; the rows are folded with row_bcast:15 (rows 0 / 2 into
+// rows 1 / 3) and row_bcast:31 (into rows 2 / 3) - all register to register; rounds 1-3 had crossed the rows through
+// ds_bpermute, an LDS round trip per round on a step that is one latency chain - and lane 63 is read with v_readlane.
+#ifndef DNP_K4_ROW_BCAST     // 0: A/B builds with the ds_bpermute rounds
+#define DNP_K4_ROW_BCAST 1
+#endif
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_u32_rows(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ Key<float> key_dpp_rows(const Key<float>& k) {
+    return Key<float>{((unsigned long long)dpp_u32_rows<CTRL, ROWMASK>((unsigned)(k.k >> 32)) << 32) | dpp_u32_rows<CTRL, ROWMASK>((unsigned)(k.k & 0xffffffffull))};
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ Key<double> key_dpp_rows(const Key<double>& k) {
+    return Key<double>{((unsigned long long)dpp_u32_rows<CTRL, ROWMASK>((unsigned)(k.a >> 32)) << 32) | dpp_u32_rows<CTRL, ROWMASK>((unsigned)(k.a & 0xffffffffull)),
+                       dpp_u32_rows<CTRL, ROWMASK>(k.lo)};
+}
+__device__ __forceinline__ unsigned readlane63(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ __forceinline__ Key<float> key_lane63(const Key<float>& k) {
+    return Key<float>{((unsigned long long)readlane63((unsigned)(k.k >> 32)) << 32) | readlane63((unsigned)(k.k & 0xffffffffull))};
+}
+__device__ __forceinline__ Key<double> key_lane63(const Key<double>& k) {
+    return Key<double>{((unsigned long long)readlane63((unsigned)(k.a >> 32)) << 32) | readlane63((unsigned)(k.a & 0xffffffffull)), readlane63(k.lo)};
+}
 template <typename F>
 __device__ __forceinline__ Key<F> wave_best(Key<F> k) {
     Key<F> o = key_dpp<0xB1>(k); if (o.beats(k)) k = o;
     o = key_dpp<0x4E>(k); if (o.beats(k)) k = o;
     o = key_dpp<0x141>(k); if (o.beats(k)) k = o;
     o = key_dpp<0x140>(k); if (o.beats(k)) k = o;
+#if DNP_K4_ROW_BCAST
+    o = key_dpp_rows<0x142, 0xa>(k); if (o.beats(k)) k = o;     // rows the mask leaves out read their own key: nothing beats itself
+    o = key_dpp_rows<0x143, 0xc>(k); if (o.beats(k)) k = o;
+    return key_lane63(k);
+#else
 #pragma unroll
     for (int off = 16; off <= 32; off <<= 1) {
         o = k.xor_lane(off);
         if (o.beats(k)) k = o;
     }
     return k;
+#endif
 }
 
 // LDS of the workgroup argmax.  fp32: three words in rotation (word (step+1)%3 was last read right after the

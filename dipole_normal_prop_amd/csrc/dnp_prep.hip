@@ -143,15 +143,28 @@ __device__ __forceinline__ void wave_argmax(double& bv, int& bj) {
     for (int off = 16; off <= 32; off <<= 1) take_better(bv, bj, __shfl_xor(bv, off, 64), __shfl_xor(bj, off, 64));
 }
 
-// the wave's maximum of bv in every lane (values only: three instructions per round instead of ten)
+// the wave's maximum of bv as a wave-uniform value (values only: three instructions per round instead of ten).  Four
+// butterfly rounds on DPP leave every 16-lane row's maximum in all of its lanes; the rows are then folded with row_bcast:15
+// (lane 15 of rows 0 / 2 into rows 1 / 3) and row_bcast:31 (lane 31 into rows 2 / 3) - register to register, where the two
+// ds_bpermute rounds of an all-lanes butterfly cost an LDS round trip each - and lane 63 is read with v_readlane.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64_rows(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(b & 0xffffffffull), (int)(unsigned)(b & 0xffffffffull), CTRL, ROWMASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(b >> 32), (int)(unsigned)(b >> 32), CTRL, ROWMASK, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_max_f64(double v) {
     v = __builtin_fmax(v, dpp_f64<0xB1>(v));
     v = __builtin_fmax(v, dpp_f64<0x4E>(v));
     v = __builtin_fmax(v, dpp_f64<0x141>(v));
     v = __builtin_fmax(v, dpp_f64<0x140>(v));
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) v = __builtin_fmax(v, __shfl_xor(v, off, 64));
-    return v;
+    v = __builtin_fmax(v, dpp_f64_rows<0x142, 0xa>(v));   // row_bcast:15 into rows 1 and 3 (the other rows keep their value)
+    v = __builtin_fmax(v, dpp_f64_rows<0x143, 0xc>(v));   // row_bcast:31 into rows 2 and 3
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffull), 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
 template <int EPL>
