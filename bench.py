@@ -254,7 +254,7 @@ def main():
         if marks is not None:
             marks[0].record()
         if tiles.fused:              # what the drivers do (field_utils._slabs_and_rows), opened up for the event marks
-            w_part = torch.empty((p_hi - p_lo, tiles.n_tiles, 2), dtype=torch.float64, device=dev)
+            w_part = torch.empty((p_hi - p_lo, tiles.n_tiles, tiles.slots), dtype=torch.float64, device=dev)
             dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part, split)
         else:
             dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, None, split)
@@ -263,7 +263,7 @@ def main():
         if tiles.fused:
             W = torch.empty((p_hi - p_lo, N_PATCHES), dtype=torch.float64, device=dev)
             fu._lib.check(fu._lib.require_device().dnp_interactions_from_tiles(
-                fu._lib.ptr(w_part), p_hi - p_lo, N_POINTS, fu._lib.ptr(point_patch), fu._lib.ptr(off), N_PATCHES,
+                fu._lib.ptr(w_part), tiles.slots, p_hi - p_lo, N_POINTS, fu._lib.ptr(point_patch), fu._lib.ptr(off), N_PATCHES,
                 fu._lib.ptr(W), fu._lib.current_stream()))
         else:
             W = fu._interaction_rows(dE, pts, off, idx)

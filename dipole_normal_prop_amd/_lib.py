@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DNP_LIB", os.path.join(_HERE, "libdnp.so"))
 
-ABI_VERSION = 400          # DNP_VERSION of include/dnp.h this binding matches (argument lists changed in 0.4.0)
+ABI_VERSION = 500          # DNP_VERSION of include/dnp.h this binding matches (0.5.0: fp64 patch-driver entry points)
 
 _c_i64 = ctypes.c_int64
 _c_p = ctypes.c_void_p
@@ -43,18 +43,24 @@ SIGNATURES = {
     "dnp_patch_tile_rows": (_c_i64, []),
     "dnp_tile_boxes_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
     "dnp_patch_fields_tiled_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64,
-                                                  ctypes.c_float, _c_p, _c_p, ctypes.c_int, _c_p, _c_sz, _c_p]),
+                                                  ctypes.c_float, _c_p, _c_p, ctypes.c_int, ctypes.c_int, _c_p, _c_sz, _c_p]),
+    "dnp_patch_fields_tiled_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64,
+                                                  ctypes.c_double, _c_p, _c_p, ctypes.c_int, _c_p]),
     "dnp_patch_exchange_bytes": (_c_sz, [_c_i64, _c_i64]),
     "dnp_exchange_init": (ctypes.c_int, [_c_p, _c_sz, _c_p]),
-    "dnp_check_tile_groups": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_p]),
-    "dnp_interactions_from_tiles": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p]),
+    "dnp_check_tile_groups": (ctypes.c_int, [_c_p, _c_i64, ctypes.c_int, _c_p, _c_p]),
+    "dnp_interactions_from_tiles": (ctypes.c_int, [_c_p, ctypes.c_int, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p]),
     "dnp_interactions_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p]),
+    "dnp_interactions_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p]),
     "dnp_combine_fields_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, ctypes.c_int, _c_p]),
     "dnp_xie_pairs_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, ctypes.c_float, ctypes.c_int,
                                          _c_p, _c_p]),
     "dnp_xie_pairs_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, ctypes.c_double, ctypes.c_int,
                                          _c_p, _c_p]),
     "dnp_xie_order_f32": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p]),
+    "dnp_xie_order_f64": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p]),
+    "dnp_xie_rowdots_f32": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
+    "dnp_xie_rowdots_f64": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
     "dnp_point_greedy_workspace_bytes": (_c_sz, [_c_i64, ctypes.c_int]),
     "dnp_point_greedy_max_points": (ctypes.c_int, []),
     "dnp_point_greedy_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_i64, ctypes.c_float, ctypes.c_int, _c_p, _c_p,
@@ -67,8 +73,14 @@ SIGNATURES = {
     "dnp_patch_greedy": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "dnp_combine_signed_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, ctypes.c_int, _c_p]),
     "dnp_patch_layout_f32": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p]),
+    "dnp_patch_layout_f64": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p]),
+    "dnp_combine_signed_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, ctypes.c_int, _c_p]),
+    "dnp_patch_finish_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64,
+                                            ctypes.c_int, _c_p]),
     "dnp_patch_finish_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64,
                                             ctypes.c_int, _c_p]),
+    "dnp_rest_finish_f32": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p]),
+    "dnp_rest_finish_f64": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p]),
     "dnp_xyz_format_bound": (_c_i64, [_c_i64, _c_i64]),
     "dnp_xyz_format_f32": (_c_i64, [_c_p, _c_i64, _c_i64, _c_p, _c_i64]),
     "dnp_xyz_parse_f32": (_c_i64, [_c_p, _c_i64, _c_p, _c_i64, _c_p]),

@@ -420,7 +420,7 @@ static int run_pairs_body(const F* src, int64_t S, int64_t ld_src, const int64_t
         if (sizeof(F) == 4 && DNP_K1_FAR && pa.far_d2 > F(0) && split == 4 && KT == kKTScalar && V == kFast &&   \
             MODE == kField)                                                                                       \
             hipLaunchKernelGGL((pair_kernel_scalar<F, double, kField, kKTScalar, kFast, (sizeof(F) == 4 && DNP_K1_FAR), \
-                                                   false, false, false, (sizeof(F) == 4 && DNP_K1_FAR) ? 4 : 1>),  \
+                                                   false, false, 0, (sizeof(F) == 4 && DNP_K1_FAR) ? 4 : 1>),  \
                                grid, dim3(kBlock), 0, stream, pa);                                                \
         else if (sizeof(F) == 4 && DNP_K1_FAR && pa.far_d2 > F(0))                                                \
             hipLaunchKernelGGL((pair_kernel_scalar<F, double, MODE, KT, V, (sizeof(F) == 4 && DNP_K1_FAR)>), grid, \

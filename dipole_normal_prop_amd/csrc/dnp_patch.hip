@@ -31,9 +31,11 @@ constexpr int kXchWaves = DNP_XCH_WAVES;
 #define DNP_FORCE_LDS 0
 #endif
 
-// W[k][j] = sum_{t in patch j} dE[k][t] . n_t    - one workgroup per (j, k), fp64 tree reduce.
-__global__ __launch_bounds__(256) void interactions_kernel(const float* __restrict__ dE, int64_t N,
-                                                           const float* __restrict__ pts, int64_t ld_pts,
+// W[k][j] = sum_{t in patch j} dE[k][t] . n_t    - one workgroup per (j, k), fp64 tree reduce.  F = the precision of the
+// slabs and the cloud: the per-point dot is taken in it (float: the reference on a float32 cloud; double: on a float64 one).
+template <typename F>
+__global__ __launch_bounds__(256) void interactions_kernel(const F* __restrict__ dE, int64_t N,
+                                                           const F* __restrict__ pts, int64_t ld_pts,
                                                            const int64_t* __restrict__ patch_off,
                                                            const int64_t* __restrict__ patch_idx, int64_t P,
                                                            double* __restrict__ W) {
@@ -41,15 +43,15 @@ __global__ __launch_bounds__(256) void interactions_kernel(const float* __restri
     // memory-side cache - walking them oldest-first would evict exactly the lines about to be read
     const int64_t j = blockIdx.x, k = (int64_t)gridDim.y - 1 - blockIdx.y;
     const int64_t lo = patch_off[j], hi = patch_off[j + 1];
-    const float* slab = dE + k * N * 3;
+    const F* slab = dE + k * N * 3;
     double s = 0.0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const int64_t t = patch_idx ? patch_idx[i] : i;   // nullptr: patches are contiguous row ranges
-        const float* e = slab + t * 3;
-        const float* n = pts + t * ld_pts + 3;
-        // per-point dot in fp32 like (E[patch] * pts[patch, 3:]).sum(dim=-1) - products rounded separately, added left to
-        // right, no fma contraction (the same statement as the pair kernel's epilogue) -, patch sum in fp64
-        float d;
+        const F* e = slab + t * 3;
+        const F* n = pts + t * ld_pts + 3;
+        // per-point dot in the cloud's precision like (E[patch] * pts[patch, 3:]).sum(dim=-1) - products rounded separately,
+        // added left to right, no fma contraction (the same statement as the pair kernel's epilogue) -, patch sum in fp64
+        F d;
         {
 #pragma clang fp contract(off)
             d = (e[0] * n[0] + e[1] * n[1]) + e[2] * n[2];
@@ -129,38 +131,43 @@ __global__ __launch_bounds__(256) void tile_box_kernel(const float* __restrict__
 }
 
 // W[k][j] = sum over the target tiles that overlap patch j of the tile's partial for j (slot 0 when j is the group of
-// the tile's first row, else slot 1), in tile order - the second half of the fused interaction matrix
+// the tile's first row; with 2 slots everything else is slot 1, with 3 slots the next group is slot 1 and the rest slot 2),
+// in tile order - the second half of the fused interaction matrix
 __global__ __launch_bounds__(256) void tile_interactions_kernel(const double* __restrict__ w_part, int64_t n_tiles,
                                                                 int rows_per_tile, const int64_t* __restrict__ point_patch,
                                                                 const int64_t* __restrict__ patch_off, int64_t P,
-                                                                int64_t K, double* __restrict__ W) {
+                                                                int64_t K, double* __restrict__ W, int slots) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
     if (j >= P || k >= K) return;
     const int64_t lo = patch_off[j], hi = patch_off[j + 1];
     double s = 0.0;
     if (hi > lo) {
         const int64_t t0 = lo / rows_per_tile, t1 = (hi - 1) / rows_per_tile;
-        const double* part = w_part + k * n_tiles * 2;
-        for (int64_t t = t0; t <= t1; ++t) s += part[t * 2 + (point_patch[t * rows_per_tile] == j ? 0 : 1)];
+        const double* part = w_part + k * n_tiles * slots;
+        for (int64_t t = t0; t <= t1; ++t) {
+            const int64_t g0 = point_patch[t * rows_per_tile];
+            const int slot = (g0 == j) ? 0 : ((slots == 3 && g0 + 1 == j) ? 1 : slots - 1);
+            s += part[t * slots + slot];
+        }
     }
     W[k * P + j] = s;
 }
 
-// the precondition of the pair kernel's interaction partials (w_part): the rows of a target tile take at most TWO group
-// values (the epilogue files a row under "the group of the tile's first row" or "the other one").  One thread per tile;
-// violations[0] += tiles that hold three or more.
+// the precondition of the pair kernel's interaction partials (w_part): the rows of a target tile take at most `slots` (2 or
+// 3) group values, and with 3 slots the second one is the first + 1 (the epilogue files a row under "the group of the tile's
+// first row", with 3 slots "that group + 1", or "the other one").  One thread per tile; violations[0] += tiles that break it.
 __global__ __launch_bounds__(256) void tile_groups_kernel(const int64_t* __restrict__ point_patch, int64_t N, int rows_per_tile,
-                                                          int64_t n_tiles, int32_t* __restrict__ violations) {
+                                                          int64_t n_tiles, int32_t* __restrict__ violations, int slots) {
     const int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= n_tiles) return;
     const int64_t r0 = tile * rows_per_tile, r1 = (r0 + rows_per_tile < N) ? r0 + rows_per_tile : N;
     const int64_t first = point_patch[r0];
-    int64_t second = first;
+    int64_t other = first;                              // the one group value that goes into the last slot
     bool bad = false;
     for (int64_t r = r0 + 1; r < r1; ++r) {
         const int64_t v = point_patch[r];
-        if (v == first || v == second) continue;
-        if (second == first) second = v; else bad = true;
+        if (v == first || (slots == 3 && v == first + 1) || v == other) continue;
+        if (other == first) other = v; else bad = true;
     }
     if (bad) atomicAdd(violations, 1);
 }
@@ -169,15 +176,16 @@ __global__ __launch_bounds__(256) void tile_groups_kernel(const int64_t* __restr
 
 extern "C" {
 
-int dnp_check_tile_groups(const int64_t* point_patch, int64_t N, int32_t* violations, void* stream) {
+int dnp_check_tile_groups(const int64_t* point_patch, int64_t N, int w_slots, int32_t* violations, void* stream) {
     clear_error();
     DNP_REQUIRE(N >= 0, "negative size");
+    DNP_REQUIRE(w_slots == 2 || w_slots == 3, "w_slots=%d (2 or 3)", w_slots);
     if (N == 0) return DNP_OK;
     DNP_REQUIRE(point_patch && violations, "NULL pointer");
     const int rows = 64 * kPatchScalarKT;
     const int64_t n_tiles = ceil_div(N, (int64_t)rows);
     hipLaunchKernelGGL(tile_groups_kernel, dim3((unsigned)ceil_div(n_tiles, 256)), dim3(256), 0, (hipStream_t)stream, point_patch,
-                       N, rows, n_tiles, violations);
+                       N, rows, n_tiles, violations, w_slots);
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
 }
@@ -198,16 +206,17 @@ int dnp_tile_boxes_f32(const float* pts, int64_t N, int64_t ld_pts, int64_t rows
 
 int64_t dnp_patch_tile_rows(void) { return 64 * kPatchScalarKT; }
 
-int dnp_interactions_from_tiles(const double* w_part, int64_t K, int64_t N, const int64_t* point_patch,
+int dnp_interactions_from_tiles(const double* w_part, int w_slots, int64_t K, int64_t N, const int64_t* point_patch,
                                 const int64_t* patch_off, int64_t P, double* W, void* stream) {
     clear_error();
     DNP_REQUIRE(K >= 0 && N >= 0 && P >= 0, "negative size");
+    DNP_REQUIRE(w_slots == 2 || w_slots == 3, "w_slots=%d (2 or 3)", w_slots);
     if (K == 0 || P == 0) return DNP_OK;
     DNP_REQUIRE(w_part && point_patch && patch_off && W, "NULL pointer");
     DNP_REQUIRE(K <= 65535, "K=%lld slabs exceed one launch (65535)", (long long)K);
     const int rows = 64 * kPatchScalarKT;
     hipLaunchKernelGGL(tile_interactions_kernel, dim3((unsigned)ceil_div(P, 256), (unsigned)K), dim3(256), 0,
-                       (hipStream_t)stream, w_part, ceil_div(N, (int64_t)rows), rows, point_patch, patch_off, P, K, W);
+                       (hipStream_t)stream, w_part, ceil_div(N, (int64_t)rows), rows, point_patch, patch_off, P, K, W, w_slots);
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
 }
@@ -237,7 +246,7 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts, cons
                                const float* patch_box, int64_t p_begin, int64_t p_end, float eps, float* dE,
                                void* stream) {
     return dnp_patch_fields_tiled_f32(pts, N, ld_pts, patch_off, patch_idx, P, point_patch, patch_box, nullptr, p_begin,
-                                      p_end, eps, dE, nullptr, 1, nullptr, 0, stream);
+                                      p_end, eps, dE, nullptr, 2, 1, nullptr, 0, stream);
 }
 
 // exchange buffer of the split forms: one record per (split patch, target tile) - the arrival counter in a 128-byte line of
@@ -258,9 +267,10 @@ int dnp_exchange_init(void* exchange, size_t bytes, void* stream) {
 int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
                                const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
                                const float* patch_box, const float* tile_box, int64_t p_begin, int64_t p_end, float eps,
-                               float* dE, double* w_part, int source_split, void* exchange, size_t exchange_bytes,
+                               float* dE, double* w_part, int w_slots, int source_split, void* exchange, size_t exchange_bytes,
                                void* stream) {
     clear_error();
+    DNP_REQUIRE(!w_part || w_slots == 2 || w_slots == 3, "w_slots=%d (2 or 3 group slots per tile)", w_slots);
     DNP_REQUIRE(source_split == 1 || (source_split < 0 && source_split >= -65535),
                 "source_split=%d (1, or -k: the last k patches of the launch as split items)", source_split);
     DNP_REQUIRE(N >= 0 && P >= 0, "negative size");
@@ -292,7 +302,7 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
         {
             const int64_t n_tiles_b = ceil_div(N, (int64_t)64 * kPatchScalarKT);
             pa.bnd.n_chunk_off = P + 1; pa.bnd.n_chunk_box = patch_box ? P : 0; pa.bnd.n_tile_box = tile_box ? n_tiles_b : 0;
-            pa.bnd.n_tgt_group = N; pa.bnd.n_w_part = w_part ? kn * n_tiles_b * 2 : 0; pa.bnd.n_partial = kn * N * 3;
+            pa.bnd.n_tgt_group = N; pa.bnd.n_w_part = w_part ? kn * n_tiles_b * w_slots : 0; pa.bnd.n_partial = kn * N * 3;
             pa.bnd.n_xch_items = exchange ? (int64_t)(exchange_bytes / (size_t)xch_item_bytes(4, kPatchScalarKT, 3)) : 0;
             pa.bnd.n_src_rows = N; pa.bnd.err = bounds_err_buffer();
         }
@@ -306,7 +316,7 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
             const int tail = (tabled && source_split < 0 && k0 == 0 && kn == K) ? (int)(-source_split < K ? -source_split : K) : 0;
             pa.chunk_box = patch_box;
             pa.tile_box = tile_box;
-            pa.w_part = w_part ? w_part + k0 * ceil_div(N, (int64_t)64 * kPatchScalarKT) * 2 : nullptr;
+            pa.w_part = w_part ? w_part + k0 * ceil_div(N, (int64_t)64 * kPatchScalarKT) * w_slots : nullptr;
             if (tail) {
                 const int64_t n_tiles = ceil_div(N, (int64_t)64 * kPatchScalarKT);
                 const size_t need = dnp_patch_exchange_bytes(N, tail);
@@ -324,20 +334,26 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
                 pa.xch_ticket = (unsigned int*)exchange;
                 pa.xch_terms = (double*)((char*)exchange + 128);
                 const dim3 tgrid((unsigned)blocks);
-                if (w_part)
-                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, true, 4, kW, true>),
+                if (w_part && w_slots == 3)
+                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, 3, 4, kW, true>),
+                                       tgrid, dim3(kW * 64), 0, st, pa);
+                else if (w_part)
+                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, 2, 4, kW, true>),
                                        tgrid, dim3(kW * 64), 0, st, pa);
                 else
-                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, false, 4, kW, true>),
+                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, 0, 4, kW, true>),
                                        tgrid, dim3(kW * 64), 0, st, pa);
             } else if (tabled) {
                 // the tabled, unsplit form runs in workgroups of kTabledWaves wavefronts (pair_kernel.h, WAVES)
                 const dim3 sgrid((unsigned)ceil_div(N, (int64_t)kTabledWaves * 64 * kPatchScalarKT), (unsigned)kn);
-                if (w_part)
-                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, true, 1, kTabledWaves>),
+                if (w_part && w_slots == 3)
+                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, 3, 1, kTabledWaves>),
+                                       sgrid, dim3(kTabledWaves * 64), 0, st, pa);
+                else if (w_part)
+                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, 2, 1, kTabledWaves>),
                                        sgrid, dim3(kTabledWaves * 64), 0, st, pa);
                 else
-                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, false, 1, kTabledWaves>),
+                    hipLaunchKernelGGL((pair_kernel_scalar<float, float, kField, kPatchScalarKT, kFast, kPatchFar, true, true, 0, 1, kTabledWaves>),
                                        sgrid, dim3(kTabledWaves * 64), 0, st, pa);
             } else {
                 const dim3 sgrid((unsigned)ceil_div(N, (int64_t)(kBlock / 64) * 64 * kPatchScalarKT), (unsigned)kn);
@@ -362,6 +378,72 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
     return DNP_OK;
 }
 
+// ---- the same slabs for a FLOAT64 cloud (round 5): the reference computes in the dtype it is handed (field_utils.py:96-109) and
+// its socket path hands it float64 (util.py:71-77), so a float64 cloud's patch fields, interaction sums and diffuse field
+// are evaluated in double - no far-field chain (its truncation is an fp32-ulp device), hence no box tables and no split tail;
+// the scalar-unit kernel at KT = 2 on the patch-sorted layout (two-wavefront workgroups, XCD-aware tile mapping, interaction
+// partials out of the epilogue), the LDS kernel for gathered patches and for eps <= 0.
+#ifndef DNP_KT64
+#define DNP_KT64 2
+#endif
+constexpr int kPatchScalarKT64 = DNP_KT64;
+static_assert(kPatchScalarKT64 == kPatchScalarKT, "w_part tiles of both precisions are dnp_patch_tile_rows() rows");
+
+int dnp_patch_fields_tiled_f64(const double* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
+                               const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
+                               int64_t p_begin, int64_t p_end, double eps, double* dE, double* w_part, int w_slots, void* stream) {
+    clear_error();
+    DNP_REQUIRE(!w_part || w_slots == 2 || w_slots == 3, "w_slots=%d (2 or 3 group slots per tile)", w_slots);
+    DNP_REQUIRE(N >= 0 && P >= 0, "negative size");
+    DNP_REQUIRE(0 <= p_begin && p_begin <= p_end && p_end <= P, "bad patch range [%lld,%lld) of %lld",
+                (long long)p_begin, (long long)p_end, (long long)P);
+    if (N == 0 || p_begin == p_end) return DNP_OK;
+    DNP_REQUIRE(pts && patch_off && point_patch && dE, "NULL pointer");   // patch_idx may be NULL (contiguous)
+    DNP_REQUIRE(ld_pts >= 6, "ld_pts=%lld < 6", (long long)ld_pts);
+    const bool scalar_path = !patch_idx && eps > 0.0;
+    DNP_REQUIRE(!w_part || scalar_path, "w_part needs the patch-sorted layout (patch_idx == NULL) and eps > 0");
+    const int64_t K = p_end - p_begin;
+    const int64_t n_tiles = ceil_div(N, (int64_t)64 * kPatchScalarKT64);
+    for (int64_t k0 = 0; k0 < K; k0 += 65535) {
+        const int64_t kn = (K - k0 < 65535) ? (K - k0) : 65535;
+        PairArgs<double, double> pa{};
+        pa.src = pts; pa.ld_src = ld_pts; pa.src_idx = patch_idx;
+        pa.tgt = pts; pa.ld_tgt = ld_pts; pa.tgt_idx = nullptr; pa.T = N;
+        pa.chunk_off_dev = patch_off; pa.chunk_base = p_begin + k0; pa.tgt_group = point_patch;
+        pa.eps = eps; pa.partial = dE + k0 * N * 3;
+        pa.far_d2 = 0.0;
+        pa.w_part = w_part ? w_part + k0 * n_tiles * w_slots : nullptr;
+        const hipStream_t st = (hipStream_t)stream;
+#ifdef DNP_BOUNDS
+        pa.bnd = PairBounds{};
+        pa.bnd.n_chunk_off = P + 1; pa.bnd.n_tgt_group = N; pa.bnd.n_w_part = w_part ? kn * n_tiles * w_slots : 0;
+        pa.bnd.n_partial = kn * N * 3; pa.bnd.n_src_rows = N; pa.bnd.err = bounds_err_buffer();
+#endif
+        if (scalar_path) {
+            const dim3 sgrid((unsigned)ceil_div(N, (int64_t)kTabledWaves * 64 * kPatchScalarKT64), (unsigned)kn);
+            if (w_part && w_slots == 3)
+                hipLaunchKernelGGL((pair_kernel_scalar<double, double, kField, kPatchScalarKT64, kFast, false, false, false, 3, 1, kTabledWaves>),
+                                   sgrid, dim3(kTabledWaves * 64), 0, st, pa);
+            else if (w_part)
+                hipLaunchKernelGGL((pair_kernel_scalar<double, double, kField, kPatchScalarKT64, kFast, false, false, false, 2, 1, kTabledWaves>),
+                                   sgrid, dim3(kTabledWaves * 64), 0, st, pa);
+            else
+                hipLaunchKernelGGL((pair_kernel_scalar<double, double, kField, kPatchScalarKT64, kFast, false, false, false, 0, 1, kTabledWaves>),
+                                   sgrid, dim3(kTabledWaves * 64), 0, st, pa);
+        } else {
+            const dim3 grid((unsigned)ceil_div(N, (int64_t)kBlock), (unsigned)kn);     // KT = 1: 116 VGPRs (KT = 4: 220, two wavefronts per SIMD)
+            if (eps > 0.0)
+                hipLaunchKernelGGL((pair_kernel<double, double, kField, 1, kFast>), grid, dim3(kBlock), 0, st, pa);
+            else if (eps == 0.0)
+                hipLaunchKernelGGL((pair_kernel<double, double, kField, 1, kNanCoinc>), grid, dim3(kBlock), 0, st, pa);
+            else
+                hipLaunchKernelGGL((pair_kernel<double, double, kField, 1, kRobust>), grid, dim3(kBlock), 0, st, pa);
+        }
+        DNP_CHECK_HIP(hipGetLastError());
+    }
+    return DNP_OK;
+}
+
 int dnp_interactions_f32(const float* dE, int64_t K, int64_t N, const float* pts, int64_t ld_pts,
                          const int64_t* patch_off, const int64_t* patch_idx, int64_t P, double* W,
                          void* stream) {
@@ -371,7 +453,22 @@ int dnp_interactions_f32(const float* dE, int64_t K, int64_t N, const float* pts
     DNP_REQUIRE(dE && pts && patch_off && W, "NULL pointer");             // patch_idx may be NULL (contiguous)
     DNP_REQUIRE(ld_pts >= 6, "ld_pts=%lld < 6", (long long)ld_pts);
     DNP_REQUIRE(K <= 65535, "K=%lld slabs exceed one launch (65535)", (long long)K);
-    hipLaunchKernelGGL(interactions_kernel, dim3((unsigned)P, (unsigned)K), dim3(256), 0, (hipStream_t)stream, dE, N,
+    hipLaunchKernelGGL(interactions_kernel<float>, dim3((unsigned)P, (unsigned)K), dim3(256), 0, (hipStream_t)stream, dE, N,
+                       pts, ld_pts, patch_off, patch_idx, P, W);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+int dnp_interactions_f64(const double* dE, int64_t K, int64_t N, const double* pts, int64_t ld_pts,
+                         const int64_t* patch_off, const int64_t* patch_idx, int64_t P, double* W,
+                         void* stream) {
+    clear_error();
+    DNP_REQUIRE(K >= 0 && N >= 0 && P >= 0, "negative size");
+    if (K == 0 || P == 0) return DNP_OK;
+    DNP_REQUIRE(dE && pts && patch_off && W, "NULL pointer");             // patch_idx may be NULL (contiguous)
+    DNP_REQUIRE(ld_pts >= 6, "ld_pts=%lld < 6", (long long)ld_pts);
+    DNP_REQUIRE(K <= 65535, "K=%lld slabs exceed one launch (65535)", (long long)K);
+    hipLaunchKernelGGL(interactions_kernel<double>, dim3((unsigned)P, (unsigned)K), dim3(256), 0, (hipStream_t)stream, dE, N,
                        pts, ld_pts, patch_off, patch_idx, P, W);
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;

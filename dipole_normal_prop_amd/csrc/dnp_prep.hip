@@ -395,14 +395,15 @@ __global__ __launch_bounds__(kGreedyBlock) void patch_greedy_block_kernel(const 
 // ---- the patch-sorted working layout in ONE launch: swork[i] = pts[idx[i]], sorted_patch[i] = p for the rows
 // i in [off[p], off[p+1]) of every patch p (one workgroup per patch); replaces a repeat_interleave (three launches), a
 // row gather and their temporaries in the drivers' set-up
-__global__ __launch_bounds__(256) void patch_layout_kernel(const float* __restrict__ pts, int64_t ld,
+template <typename F>
+__global__ __launch_bounds__(256) void patch_layout_kernel(const F* __restrict__ pts, int64_t ld,
                                                            const int64_t* __restrict__ off,
-                                                           const int64_t* __restrict__ idx, float* __restrict__ swork,
+                                                           const int64_t* __restrict__ idx, F* __restrict__ swork,
                                                            int64_t* __restrict__ sorted_patch) {
     const int64_t p = blockIdx.x, lo = off[p], hi = off[p + 1];
     for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
-        const float* r = pts + idx[i] * ld;
-        float* o = swork + i * 6;
+        const F* r = pts + idx[i] * ld;
+        F* o = swork + i * 6;
         o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = r[4]; o[5] = r[5];
         sorted_patch[i] = p;
     }
@@ -414,39 +415,65 @@ __global__ __launch_bounds__(256) void patch_layout_kernel(const float* __restri
 //   diffuse and listed[patch(t)]:  n *= ((float)E64[t] . n > 0) ? +1 : -1     (fp32 products, summed in order)
 //   weights:  n /= w[t]
 //   out[perm[t]] (row stride ld_out, columns 3..5) = n        - the caller's point order and tensor
-template <typename OUT>
-__global__ __launch_bounds__(256) void patch_finish_kernel(const float* __restrict__ work, int64_t ld, int64_t N,
+// F = the working cloud's precision (float / double: the field is rounded to it before the dot, as the reference's E is
+// held in the cloud's dtype), OUT = the caller's tensor.
+template <typename F, typename OUT>
+__global__ __launch_bounds__(256) void patch_finish_kernel(const F* __restrict__ work, int64_t ld, int64_t N,
                                                            const int64_t* __restrict__ point_patch,
                                                            const double* __restrict__ sigma,
                                                            const double* __restrict__ E64,
                                                            const unsigned char* __restrict__ listed,
-                                                           const float* __restrict__ weights,
+                                                           const F* __restrict__ weights,
                                                            const int64_t* __restrict__ perm, OUT* __restrict__ out,
                                                            int64_t ld_out) {
+#pragma clang fp contract(off)
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= N) return;
-    const float* r = work + t * ld;
-    float n0 = r[3], n1 = r[4], n2 = r[5];
+    const F* r = work + t * ld;
+    F n0 = r[3], n1 = r[4], n2 = r[5];
     const int64_t k = point_patch[t];
     if (k >= 0) {
-        const float sg = (float)sigma[k];
+        const F sg = (F)sigma[k];
         n0 *= sg; n1 *= sg; n2 *= sg;
         if (E64 && (!listed || listed[k])) {
-            const float e0 = (float)E64[t * 3 + 0], e1 = (float)E64[t * 3 + 1], e2 = (float)E64[t * 3 + 2];
-            const float dot = __fadd_rn(__fadd_rn(__fmul_rn(e0, n0), __fmul_rn(e1, n1)), __fmul_rn(e2, n2));
-            const float s = dot > 0.f ? 1.f : -1.f;
+            const F e0 = (F)E64[t * 3 + 0], e1 = (F)E64[t * 3 + 1], e2 = (F)E64[t * 3 + 2];
+            const F dot = (e0 * n0 + e1 * n1) + e2 * n2;       // products rounded separately, added in order (contraction off)
+            const F s = dot > F(0) ? F(1) : F(-1);
             n0 *= s; n1 *= s; n2 *= s;
         }
     }
-    if (weights) { const float w = weights[t]; n0 = n0 / w; n1 = n1 / w; n2 = n2 / w; }
+    if (weights) { const F w = weights[t]; n0 = n0 / w; n1 = n1 / w; n2 = n2 / w; }
     OUT* o = out + (perm ? perm[t] : t) * ld_out;
     o[3] = (OUT)n0; o[4] = (OUT)n1; o[5] = (OUT)n2;
+}
+
+// ---- the tail of the representatives driver for the points that are NOT representatives, in ONE launch
+// (field_utils.py:251-252: a flipped patch flips its rest points too; :273-276: every non-representative point then takes the
+// sign of the field E of all representatives): for entry i of patch p's rest list, row = rest_idx[i],
+//   n = work[row].n * sigma[p];   n *= (E[i] . n > 0) ? +1 : -1      (products rounded separately, added in order)
+// in place.  One workgroup per patch; every point is listed once (the callers' partition).  Replaces a segmented count, a
+// parity, two gathers and five elementwise torch launches (~14 launches, round 5: profiles/r05_config3_kernels.txt).
+template <typename F>
+__global__ __launch_bounds__(256) void rest_finish_kernel(F* __restrict__ work, int64_t ld, const int64_t* __restrict__ rest_off,
+                                                          const int64_t* __restrict__ rest_idx, const double* __restrict__ sigma,
+                                                          const F* __restrict__ E) {
+#pragma clang fp contract(off)
+    const int64_t p = blockIdx.x, lo = rest_off[p], hi = rest_off[p + 1];
+    const F sg = (F)sigma[p];
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        F* r = work + rest_idx[i] * ld;
+        F n0 = r[3] * sg, n1 = r[4] * sg, n2 = r[5] * sg;
+        const F dot = (E[i * 3 + 0] * n0 + E[i * 3 + 1] * n1) + E[i * 3 + 2] * n2;
+        const F s = dot > F(0) ? F(1) : F(-1);
+        r[3] = n0 * s; r[4] = n1 * s; r[5] = n2 * s;
+    }
 }
 
 // E64[t][c] (+)= sum_k sigma[k] * dE[k][t][c] over the K slabs held here, accumulated in fp64 in slab order.
 // sigma is +-1, so every product is exact; a fp64 sum of a few thousand fp32 values is independent of the
 // order to ~1e-16 relative, hence the same on one GPU and on eight.
-__global__ __launch_bounds__(256) void combine_signed_kernel(const float* __restrict__ dE, int64_t K, int64_t N3,
+template <typename F>
+__global__ __launch_bounds__(256) void combine_signed_kernel(const F* __restrict__ dE, int64_t K, int64_t N3,
                                                              const double* __restrict__ sigma,
                                                              double* __restrict__ E, int accumulate) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -454,8 +481,8 @@ __global__ __launch_bounds__(256) void combine_signed_kernel(const float* __rest
     double e = accumulate ? E[i] : 0.0;
     int64_t k = 0;
     for (; k + 4 <= K; k += 4) {                      // 4 independent loads in flight, added in slab order
-        const float v0 = dE[(k + 0) * N3 + i], v1 = dE[(k + 1) * N3 + i], v2 = dE[(k + 2) * N3 + i],
-                    v3 = dE[(k + 3) * N3 + i];
+        const F v0 = dE[(k + 0) * N3 + i], v1 = dE[(k + 1) * N3 + i], v2 = dE[(k + 2) * N3 + i],
+                v3 = dE[(k + 3) * N3 + i];
         e += sigma[k + 0] * (double)v0; e += sigma[k + 1] * (double)v1;
         e += sigma[k + 2] * (double)v2; e += sigma[k + 3] * (double)v3;
     }
@@ -544,7 +571,23 @@ int dnp_combine_signed_f32(const float* dE, int64_t K, int64_t N, const double* 
     DNP_REQUIRE(E, "NULL E");
     DNP_REQUIRE(K == 0 || (dE && sigma), "NULL pointer");
     const int64_t N3 = N * 3;
-    hipLaunchKernelGGL(combine_signed_kernel, dim3((unsigned)ceil_div(N3, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(combine_signed_kernel<float>, dim3((unsigned)ceil_div(N3, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dE, K, N3, sigma ? sigma + p_lo : nullptr, E, accumulate);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+int dnp_combine_signed_f64(const double* dE, int64_t K, int64_t N, const double* sigma, int64_t P, int64_t p_lo,
+                           double* E, int accumulate, void* stream) {
+    clear_error();
+    DNP_REQUIRE(K >= 0 && N >= 0 && P >= 0, "negative size");
+    DNP_REQUIRE(p_lo >= 0 && p_lo + K <= P, "slabs [%lld,%lld) outside the %lld patches", (long long)p_lo,
+                (long long)(p_lo + K), (long long)P);
+    if (N == 0) return DNP_OK;
+    DNP_REQUIRE(E, "NULL E");
+    DNP_REQUIRE(K == 0 || (dE && sigma), "NULL pointer");
+    const int64_t N3 = N * 3;
+    hipLaunchKernelGGL(combine_signed_kernel<double>, dim3((unsigned)ceil_div(N3, 256)), dim3(256), 0, (hipStream_t)stream,
                        dE, K, N3, sigma ? sigma + p_lo : nullptr, E, accumulate);
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
@@ -557,7 +600,20 @@ int dnp_patch_layout_f32(const float* pts, int64_t ld_pts, const int64_t* patch_
     if (P == 0) return DNP_OK;
     DNP_REQUIRE(pts && patch_off && patch_idx && swork && sorted_patch, "NULL pointer");
     DNP_REQUIRE(ld_pts >= 6, "ld_pts=%lld < 6", (long long)ld_pts);
-    hipLaunchKernelGGL(patch_layout_kernel, dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pts, ld_pts, patch_off,
+    hipLaunchKernelGGL(patch_layout_kernel<float>, dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pts, ld_pts, patch_off,
+                       patch_idx, swork, sorted_patch);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+int dnp_patch_layout_f64(const double* pts, int64_t ld_pts, const int64_t* patch_off, const int64_t* patch_idx,
+                         int64_t P, double* swork, int64_t* sorted_patch, void* stream) {
+    clear_error();
+    DNP_REQUIRE(P >= 0, "negative P");
+    if (P == 0) return DNP_OK;
+    DNP_REQUIRE(pts && patch_off && patch_idx && swork && sorted_patch, "NULL pointer");
+    DNP_REQUIRE(ld_pts >= 6, "ld_pts=%lld < 6", (long long)ld_pts);
+    hipLaunchKernelGGL(patch_layout_kernel<double>, dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pts, ld_pts, patch_off,
                        patch_idx, swork, sorted_patch);
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
@@ -573,11 +629,56 @@ int dnp_patch_finish_f32(const float* work, int64_t ld_work, int64_t N, const in
     DNP_REQUIRE(ld_work >= 6 && ld_out >= 6, "row stride < 6");
     const dim3 grid((unsigned)ceil_div(N, 256));
     if (out_is_f64)
-        hipLaunchKernelGGL((patch_finish_kernel<double>), grid, dim3(256), 0, (hipStream_t)stream, work, ld_work, N,
+        hipLaunchKernelGGL((patch_finish_kernel<float, double>), grid, dim3(256), 0, (hipStream_t)stream, work, ld_work, N,
                            point_patch, sigma, E64, listed, weights, perm, (double*)out, ld_out);
     else
-        hipLaunchKernelGGL((patch_finish_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, work, ld_work, N,
+        hipLaunchKernelGGL((patch_finish_kernel<float, float>), grid, dim3(256), 0, (hipStream_t)stream, work, ld_work, N,
                            point_patch, sigma, E64, listed, weights, perm, (float*)out, ld_out);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+int dnp_patch_finish_f64(const double* work, int64_t ld_work, int64_t N, const int64_t* point_patch,
+                         const double* sigma, const double* E64, const unsigned char* listed, const double* weights,
+                         const int64_t* perm, void* out, int64_t ld_out, int out_is_f64, void* stream) {
+    clear_error();
+    DNP_REQUIRE(N >= 0, "negative N");
+    if (N == 0) return DNP_OK;
+    DNP_REQUIRE(work && point_patch && sigma && out, "NULL pointer");
+    DNP_REQUIRE(ld_work >= 6 && ld_out >= 6, "row stride < 6");
+    const dim3 grid((unsigned)ceil_div(N, 256));
+    if (out_is_f64)
+        hipLaunchKernelGGL((patch_finish_kernel<double, double>), grid, dim3(256), 0, (hipStream_t)stream, work, ld_work, N,
+                           point_patch, sigma, E64, listed, weights, perm, (double*)out, ld_out);
+    else
+        hipLaunchKernelGGL((patch_finish_kernel<double, float>), grid, dim3(256), 0, (hipStream_t)stream, work, ld_work, N,
+                           point_patch, sigma, E64, listed, weights, perm, (float*)out, ld_out);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+int dnp_rest_finish_f32(float* work, int64_t ld_work, const int64_t* rest_off, const int64_t* rest_idx, int64_t P,
+                        const double* sigma, const float* E, void* stream) {
+    clear_error();
+    DNP_REQUIRE(P >= 0, "negative P");
+    if (P == 0) return DNP_OK;
+    DNP_REQUIRE(work && rest_off && rest_idx && sigma && E, "NULL pointer");
+    DNP_REQUIRE(ld_work >= 6, "row stride < 6");
+    hipLaunchKernelGGL(rest_finish_kernel<float>, dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, work, ld_work, rest_off,
+                       rest_idx, sigma, E);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+int dnp_rest_finish_f64(double* work, int64_t ld_work, const int64_t* rest_off, const int64_t* rest_idx, int64_t P,
+                        const double* sigma, const double* E, void* stream) {
+    clear_error();
+    DNP_REQUIRE(P >= 0, "negative P");
+    if (P == 0) return DNP_OK;
+    DNP_REQUIRE(work && rest_off && rest_idx && sigma && E, "NULL pointer");
+    DNP_REQUIRE(ld_work >= 6, "row stride < 6");
+    hipLaunchKernelGGL(rest_finish_kernel<double>, dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, work, ld_work, rest_off,
+                       rest_idx, sigma, E);
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
 }

@@ -1,6 +1,7 @@
 // dnp_xie.hip - the fork's "xie" pair functions:
 //   xie_field / xie_intersaction  (field_utils.py:431-469, :509-519)  -> dnp_xie_pairs_f32/_f64
-//   xie_propagation_points_in_order (field_utils.py:569-605)           -> dnp_xie_order_f32
+//   xie_propagation_points_in_order (field_utils.py:569-605)           -> dnp_xie_order_f32/_f64, its diffuse pass (:597-603)
+//                                                                          -> dnp_xie_rowdots_f32/_f64
 //
 // xie_pairs: the per-pair "reflected normal"  ref[t][s] = (n_s - C (n_s.r^) r^) / |r|^3,  r = x_s - x_t,
 // not divided when |r| == 0 (so a coincident pair yields n_s itself), and its projection on the target
@@ -128,20 +129,23 @@ __global__ __launch_bounds__(kXieBlock) void xie_pairs_kernel(const XieArgs<F> a
 
 constexpr int kOrderThreads = 1024;
 
-__global__ __launch_bounds__(kOrderThreads) void xie_order_kernel(const float* __restrict__ M, int64_t N,
+// F = the matrix's precision (float; double for float64 clouds, round 5): products rounded in F as the reference's
+// interaction_mat[idx] * weights, row sums in fp64, the sum rounded to F before its sign is taken.
+template <typename F>
+__global__ __launch_bounds__(kOrderThreads) void xie_order_kernel(const F* __restrict__ M, int64_t N,
                                                                  const int64_t* __restrict__ order,
-                                                                 float* __restrict__ weights,
-                                                                 float* __restrict__ inter) {
+                                                                 F* __restrict__ weights,
+                                                                 F* __restrict__ inter) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t* ord = order + (int64_t)blockIdx.x * N;
-    float* w = weights + (int64_t)blockIdx.x * N;
-    float* out = inter + (int64_t)blockIdx.x * N;
+    F* w = weights + (int64_t)blockIdx.x * N;
+    F* out = inter + (int64_t)blockIdx.x * N;
     __shared__ double part[kOrderThreads / 64];
-    for (int64_t j = tid; j < N; j += kOrderThreads) { w[j] = 0.f; out[j] = 0.f; }
+    for (int64_t j = tid; j < N; j += kOrderThreads) { w[j] = F(0); out[j] = F(0); }
     __syncthreads();
     for (int64_t i = 0; i < N; ++i) {
         const int64_t idx = ord[i];
-        const float* row = M + idx * N;
+        const F* row = M + idx * N;
         double s = 0.0;
         for (int64_t j = tid; j < N; j += kOrderThreads) s += (double)(row[j] * w[j]);
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -150,33 +154,33 @@ __global__ __launch_bounds__(kOrderThreads) void xie_order_kernel(const float* _
         if (tid == 0) {
             double tot = 0.0;
             for (int k = 0; k < kOrderThreads / 64; ++k) tot += part[k];
-            const float v = (float)tot;
+            const F v = (F)tot;
             out[idx] = v;
-            w[idx] = (v < 0.f) ? -1.f : 1.f;
+            w[idx] = (v < F(0)) ? F(-1) : F(1);
         }
         __syncthreads();   // w[idx] is visible to the whole workgroup before the next row is weighted
     }
 }
 
 // VPT columns per thread (N <= 1024 * VPT)
-template <int VPT>
-__global__ __launch_bounds__(kOrderThreads) void xie_order_reg_kernel(const float* __restrict__ M, int64_t N,
+template <typename F, int VPT>
+__global__ __launch_bounds__(kOrderThreads) void xie_order_reg_kernel(const F* __restrict__ M, int64_t N,
                                                                      const int64_t* __restrict__ order,
-                                                                     float* __restrict__ weights,
-                                                                     float* __restrict__ inter) {
+                                                                     F* __restrict__ weights,
+                                                                     F* __restrict__ inter) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t* ord = order + (int64_t)blockIdx.x * N;
-    float* out = inter + (int64_t)blockIdx.x * N;
+    F* out = inter + (int64_t)blockIdx.x * N;
     __shared__ double part[2][kOrderThreads / 64];
-    float w[VPT], cur[VPT], nxt[VPT];
+    F w[VPT], cur[VPT], nxt[VPT];
 #pragma unroll
-    for (int k = 0; k < VPT; ++k) { w[k] = 0.f; nxt[k] = 0.f; }
+    for (int k = 0; k < VPT; ++k) { w[k] = F(0); nxt[k] = F(0); }
     // interactions = torch.zeros(T, N) in the reference (field_utils.py:581): an order row that is not a full permutation
     // (a repeated index) leaves entries unvisited, and they must read 0, not whatever the caller's buffer held (round-3
     // advisor: field_utils passes torch.empty).  The stores of the loop below come after the loop's first barrier.
-    for (int64_t j = tid; j < N; j += kOrderThreads) out[j] = 0.f;
-    auto fetch = [&](int64_t idx, float (&dst)[VPT]) {
-        const float* row = M + idx * N;
+    for (int64_t j = tid; j < N; j += kOrderThreads) out[j] = F(0);
+    auto fetch = [&](int64_t idx, F (&dst)[VPT]) {
+        const F* row = M + idx * N;
 #pragma unroll
         for (int k = 0; k < VPT; ++k) {
             const int64_t j = tid + (int64_t)k * kOrderThreads;
@@ -199,8 +203,8 @@ __global__ __launch_bounds__(kOrderThreads) void xie_order_reg_kernel(const floa
         double tot = 0.0;
 #pragma unroll
         for (int k = 0; k < kOrderThreads / 64; ++k) tot += p[k];
-        const float v = (float)tot;
-        const float sign = (v < 0.f) ? -1.f : 1.f;
+        const F v = (F)tot;
+        const F sign = (v < F(0)) ? F(-1) : F(1);
         if (tid == (int)(idx % kOrderThreads)) {
             const int kk = (int)(idx / kOrderThreads);
 #pragma unroll
@@ -211,11 +215,41 @@ __global__ __launch_bounds__(kOrderThreads) void xie_order_reg_kernel(const floa
         for (int k = 0; k < VPT; ++k) cur[k] = nxt[k];
         idx = idx_next;
     }
-    float* wout = weights + (int64_t)blockIdx.x * N;
+    F* wout = weights + (int64_t)blockIdx.x * N;
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
         const int64_t j = tid + (int64_t)k * kOrderThreads;
         if (j < N) wout[j] = w[k];
+    }
+}
+
+// ---- the diffuse pass of the ordered propagation (field_utils.py:597-603): out[r][i] = sum_j M[i][j] * w[r][j] for the R final
+// weight vectors at once - one pass over the N x N matrix (HBM-bound: 4 N^2 bytes), one wavefront per matrix row, up to kDotOrders
+// weight vectors per pass (they stay in cache: R N values).  Products rounded in F, sums in fp64 in a fixed order (lane-strided
+// partial sums, then the butterfly), the result rounded to F.  (Rounds 1-4 ran this as a torch matmul - the one rocBLAS call on
+// the path.)
+constexpr int kDotOrders = 8;
+template <typename F>
+__global__ __launch_bounds__(256) void xie_rowdots_kernel(const F* __restrict__ M, int64_t N, const F* __restrict__ weights,
+                                                          int64_t R, int64_t r0, F* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int nr = (int)((R - r0) < kDotOrders ? (R - r0) : kDotOrders);
+    const F* row = M + i * N;
+    double s[kDotOrders];
+#pragma unroll
+    for (int r = 0; r < kDotOrders; ++r) s[r] = 0.0;
+    for (int64_t j = lane; j < N; j += 64) {
+        const F m = row[j];
+#pragma unroll
+        for (int r = 0; r < kDotOrders; ++r)
+            if (r < nr) s[r] += (double)(m * weights[(r0 + r) * N + j]);
+    }
+#pragma unroll
+    for (int r = 0; r < kDotOrders; ++r) {
+        for (int off = 32; off > 0; off >>= 1) s[r] += __shfl_xor(s[r], off, 64);
+        if (lane == 0 && r < nr) out[(r0 + r) * N + i] = (F)s[r];
     }
 }
 
@@ -241,6 +275,42 @@ static int run_xie_pairs(const F* src, int64_t S, int64_t ld_src, const F* tgt, 
 
 using namespace dnp;
 
+template <typename F>
+static int run_xie_order(const F* M, int64_t N, const int64_t* order, int64_t R, F* weights, F* inter, hipStream_t stream) {
+    clear_error();
+    DNP_REQUIRE(N >= 0 && R >= 0, "negative size");
+    if (N == 0 || R == 0) return DNP_OK;
+    DNP_REQUIRE(M && order && weights && inter, "NULL pointer");
+#ifndef DNP_XIE_ORDER_PLAIN      // A/B builds: the plain form for every size
+#define DNP_XIE_ORDER_PLAIN 0
+#endif
+    // register form: the weights of a thread's columns live in VGPRs (1024 threads per workgroup: <= 128 VGPRs each, so
+    // fp64 stops at 12 columns per thread)
+    constexpr bool f64 = sizeof(F) == 8;
+    if (!DNP_XIE_ORDER_PLAIN && N <= 4 * kOrderThreads)
+        hipLaunchKernelGGL((xie_order_reg_kernel<F, 4>), dim3((unsigned)R), dim3(kOrderThreads), 0, stream, M, N, order, weights, inter);
+    else if (!DNP_XIE_ORDER_PLAIN && f64 && N <= 12 * kOrderThreads)
+        hipLaunchKernelGGL((xie_order_reg_kernel<F, f64 ? 12 : 16>), dim3((unsigned)R), dim3(kOrderThreads), 0, stream, M, N, order, weights, inter);
+    else if (!DNP_XIE_ORDER_PLAIN && !f64 && N <= 16 * kOrderThreads)
+        hipLaunchKernelGGL((xie_order_reg_kernel<F, 16>), dim3((unsigned)R), dim3(kOrderThreads), 0, stream, M, N, order, weights, inter);
+    else
+        hipLaunchKernelGGL(xie_order_kernel<F>, dim3((unsigned)R), dim3(kOrderThreads), 0, stream, M, N, order, weights, inter);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+template <typename F>
+static int run_xie_rowdots(const F* M, int64_t N, const F* weights, int64_t R, F* out, hipStream_t stream) {
+    clear_error();
+    DNP_REQUIRE(N >= 0 && R >= 0, "negative size");
+    if (N == 0 || R == 0) return DNP_OK;
+    DNP_REQUIRE(M && weights && out, "NULL pointer");
+    for (int64_t r0 = 0; r0 < R; r0 += kDotOrders)
+        hipLaunchKernelGGL(xie_rowdots_kernel<F>, dim3((unsigned)ceil_div(N, (int64_t)4)), dim3(256), 0, stream, M, N, weights, R, r0, out);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
 extern "C" {
 
 int dnp_xie_pairs_f32(const float* src, int64_t S, int64_t ld_src, const float* tgt, int64_t T, int64_t ld_tgt,
@@ -255,24 +325,20 @@ int dnp_xie_pairs_f64(const double* src, int64_t S, int64_t ld_src, const double
 
 int dnp_xie_order_f32(const float* M, int64_t N, const int64_t* order, int64_t R, float* weights, float* inter,
                       void* stream) {
-    clear_error();
-    DNP_REQUIRE(N >= 0 && R >= 0, "negative size");
-    if (N == 0 || R == 0) return DNP_OK;
-    DNP_REQUIRE(M && order && weights && inter, "NULL pointer");
-#ifndef DNP_XIE_ORDER_PLAIN      // A/B builds: the plain form for every size
-#define DNP_XIE_ORDER_PLAIN 0
-#endif
-    if (!DNP_XIE_ORDER_PLAIN && N <= 4 * kOrderThreads)
-        hipLaunchKernelGGL(xie_order_reg_kernel<4>, dim3((unsigned)R), dim3(kOrderThreads), 0, (hipStream_t)stream, M, N, order,
-                           weights, inter);
-    else if (!DNP_XIE_ORDER_PLAIN && N <= 16 * kOrderThreads)
-        hipLaunchKernelGGL(xie_order_reg_kernel<16>, dim3((unsigned)R), dim3(kOrderThreads), 0, (hipStream_t)stream, M, N, order,
-                           weights, inter);
-    else
-        hipLaunchKernelGGL(xie_order_kernel, dim3((unsigned)R), dim3(kOrderThreads), 0, (hipStream_t)stream, M, N, order,
-                           weights, inter);
-    DNP_CHECK_HIP(hipGetLastError());
-    return DNP_OK;
+    return run_xie_order<float>(M, N, order, R, weights, inter, (hipStream_t)stream);
+}
+
+int dnp_xie_order_f64(const double* M, int64_t N, const int64_t* order, int64_t R, double* weights, double* inter,
+                      void* stream) {
+    return run_xie_order<double>(M, N, order, R, weights, inter, (hipStream_t)stream);
+}
+
+int dnp_xie_rowdots_f32(const float* M, int64_t N, const float* weights, int64_t R, float* out, void* stream) {
+    return run_xie_rowdots<float>(M, N, weights, R, out, (hipStream_t)stream);
+}
+
+int dnp_xie_rowdots_f64(const double* M, int64_t N, const double* weights, int64_t R, double* out, void* stream) {
+    return run_xie_rowdots<double>(M, N, weights, R, out, (hipStream_t)stream);
 }
 
 }  // extern "C"

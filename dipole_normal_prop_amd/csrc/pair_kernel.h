@@ -179,7 +179,7 @@ struct PairArgs {
     const F* chunk_box;      // [chunks][6] bounding boxes (lo xyz, hi xyz) of the chunks' sources, or nullptr: found by the workgroup
     F far_d2;                // scalar kernel, FAR: squared box distance beyond which the one-transcendental chain runs
     const F* tile_box;       // scalar kernel, TBOX: [ceil(T / (64 KT))][6] boxes of the wavefronts' target tiles (dnp_tile_boxes_f32)
-    double* w_part;          // scalar kernel, WPART: [gridDim.y][ceil(T / (64 KT))][2] per-(slab, tile) interaction partials
+    double* w_part;          // scalar kernel, WPART: [gridDim.y][ceil(T / (64 KT))][WPART] per-(slab, tile) interaction partials
     int split_from;          // scalar kernel, XCH: chunks [split_from, n) of the launch are evaluated with the source split
     int n_chunks;            // scalar kernel, XCH: chunks of the launch (its grid is 1-D)
     // XCH: the exchange buffer, one record per (split chunk, target tile) item: [arrival counter, padded to a 128-byte line]
@@ -199,6 +199,10 @@ template <> struct Math<float> {
     static __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
     static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
     static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+    // the kFast chain's root and reciprocal (fp32: the hardware's own, 1 ulp; fp64: refined, see Math<double>)
+    static __device__ __forceinline__ float sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+    static __device__ __forceinline__ float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
     static constexpr float kTiny = 1.17549435e-38f;   // FLT_MIN
     static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     static constexpr float kHuge = 1e30f;   // (1e30)^1.5 overflows fp32 -> w = rcp(inf) = 0
@@ -208,10 +212,36 @@ template <> struct Math<double> {
     static __device__ __forceinline__ double rsq(double x) { return 1.0 / __builtin_sqrt(x); }
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double sqrt(double x) { return __builtin_sqrt(x); }
+    // Round 5: the fp64 kFast chain and the potential no longer go through the compiler's IEEE sqrt / division (a v_rsq_f64 or
+    // v_rcp_f64 + ~12 fp64 instructions each: the 100 000^2 field took 14.5 ms, profiles/r05_f64_time.txt).  v_rsq_f64 /
+    // v_rcp_f64 are 2^29-ulp approximations (relative error <= 2^-23, the ISA manual's figure); ONE third-order step takes that
+    // to ~2^-69 - below half an ulp, so the result is the rounding of the exact value but for the last-place ties a fused
+    // evaluation cannot see:
+    //   rsq:  e = 1 - x y^2,  y' = y (1 + e/2 + 3 e^2/8)        5 fp64 instructions + the transcendental
+    //   rcp:  e = 1 - x r,    r' = r (1 + e + e^2)              3 + 1
+    // (tools/ubench_f64.hip: v_fma_f64 4.3 cycles per wave64 instruction at 8 wavefronts per SIMD, the fp64 transcendentals 16.2;
+    // 28 fma + rsq + rcp per pair mixes at 5.0 cycles per instruction.)  Arguments must be finite and positive: 0, inf and NaN
+    // come back as NaN (0 * inf in the step), which is why sqrt_fast clamps its argument and the padding rows sit at 1e50.
+    static __device__ __forceinline__ double rsq_fast(double x) {
+        const double y = __builtin_amdgcn_rsq(x);
+        const double t = x * y;
+        const double e = __builtin_fma(-t, y, 1.0);
+        const double p = __builtin_fma(0.375, e, 0.5);
+        return __builtin_fma(y * e, p, y);
+    }
+    static __device__ __forceinline__ double sqrt_fast(double x) {     // sqrt(0) = 0 exactly (the coincident pair of kFast)
+        return x * rsq_fast(__builtin_fmax(x, 2.2250738585072014e-308));
+    }
+    static __device__ __forceinline__ double rcp_fast(double x) {
+        const double r = __builtin_amdgcn_rcp(x);
+        const double e = __builtin_fma(-x, r, 1.0);
+        return __builtin_fma(r, __builtin_fma(e, e, e), r);
+    }
     static constexpr double kTiny = 2.2250738585072014e-308;   // DBL_MIN
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static constexpr double kHuge = 1e250;  // (1e250)^1.5 overflows fp64
-    static constexpr double kFar = 1e150;   // d2 = 3e300 finite, d^3 = inf
+    static constexpr double kFar = 1e50;    // padding source position: every intermediate of the refined chains stays finite
+                                            // (d2 = 3e100, d2 (|r|^3 + eps) = 1.5e251), the zero dipole makes the pair contribute 0
 };
 
 // Variants of the per-pair chain (template parameter V of pair_field / pair_kernel):
@@ -236,9 +266,9 @@ __device__ __forceinline__ void pair_field(F sx, F sy, F sz, F px, F py, F pz, F
     const F pr = M::fma(pz, rz, M::fma(py, ry, px * rx));
     F w, a;
     if (V == kFast) {
-        const F d = M::sqrt(d2);
+        const F d = M::sqrt_fast(d2);
         const F den = M::fma(d2, d, eps);
-        const F q = M::rcp(M::fma(d2, den, M::kTiny));
+        const F q = M::rcp_fast(M::fma(d2, den, M::kTiny));
         w = d2 * q;
         a = pr * q;
     } else {
@@ -348,7 +378,7 @@ __device__ __forceinline__ void pair_potential(F sx, F sy, F sz, F px, F py, F p
     using M = Math<F>;
     const F rx = sx - tx, ry = sy - ty, rz = sz - tz;
     const F d2 = M::fma(rz, rz, M::fma(ry, ry, rx * rx));
-    const F inv = M::rsq(d2);                       // d2 == 0 -> inf, pr == 0 -> 0*inf = NaN (as 0/0)
+    const F inv = M::rsq_fast(d2);                  // d2 == 0 -> inf (fp64: NaN), pr == 0 -> 0*inf = NaN (as 0/0)
     const F pr = M::fma(pz, rz, M::fma(py, ry, px * rx));
     phi = M::fma(pr, inv * inv * inv, phi);
 }
@@ -605,9 +635,11 @@ __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, cons
 }
 
 // TBOX: the box of a wavefront's 64 KT targets comes from a.tile_box (one table per cloud) instead of 36 cross-lane
-// min / max steps per (wavefront, chunk).  WPART (patch mode, cloud sorted by patch, every tile inside <= 2 groups): the
-// epilogue also leaves sum_t dE[t] . n_t of the tile's targets, split by group (the tile's first group / the other one),
-// in a.w_part - the patch interaction matrix W then needs no second pass over the slabs (dnp_interactions_from_tiles).
+// min / max steps per (wavefront, chunk).  WPART = 2 or 3 (patch mode, cloud sorted by patch, every tile inside <= WPART
+// groups; 0 = off): the epilogue also leaves sum_t dE[t] . n_t of the tile's targets, split by group (2: the tile's first
+// group / the other one; 3, round 5: first / first + 1 / the rest - patches of 100..127 points, the reference's own grid
+// partitions, put three groups into a 128-row tile), in a.w_part - the patch interaction matrix W then needs no second pass
+// over the slabs (dnp_interactions_from_tiles).
 //
 // SS (1, 2, 4): SOURCE SPLIT.  With SS = 1 the wavefronts of a workgroup own one target tile each and run the whole
 // chunk; with SS > 1 a tile's chunk is evaluated by SS wavefronts and the partial sums are added IN A FIXED ORDER - the
@@ -640,12 +672,13 @@ __device__ __forceinline__ void scalar_field_run(const F* __restrict__ src, cons
 // then start together on one CU, and split items in workgroups of 1 or 2 wavefronts cost +25 % instead of +4 %
 // (profiles/r04_xch_ab.txt).
 template <typename F, typename PT, int MODE, int KT, int V, bool FAR = false, bool BOX = false, bool TBOX = false,
-          bool WPART = false, int SS = 1, int WAVES = kBlock / 64, bool XCH = false>
+          int WPART = 0, int SS = 1, int WAVES = kBlock / 64, bool XCH = false>
 __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<F, PT> a) {
     using M = Math<F>;
     constexpr int NC = (MODE == kField) ? 3 : 1;
     constexpr bool kFarPath = FAR && MODE == kField && V == kFast;
     static_assert(SS == 1 || SS == 2 || SS == 4, "source split: 1, 2 or 4 wavefronts per target tile");
+    static_assert(WPART == 0 || WPART == 2 || WPART == 3, "interaction partials: off, or 2 / 3 group slots per tile");
     static_assert(SS == 1 || MODE == kField, "the source split is built for the field mode");
     static_assert(XCH || (WAVES % SS == 0 && WAVES >= SS), "a workgroup holds whole target tiles");
     constexpr int kTG = XCH ? WAVES : WAVES / SS;           // target tiles per workgroup (XCH: of an unsplit workgroup)
@@ -998,8 +1031,9 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
 #endif
     const int64_t chunk_id = a.chunk_base + chunk;
     double w_first = 0.0, w_other = 0.0;                  // WPART: this lane's share of the tile's interaction sums
+    double w_second = 0.0;                                 // WPART == 3: the group behind the tile's first one
     int64_t g_first = 0;
-    if constexpr (WPART) {                                  // group of the tile's first target (wave-uniform)
+    if constexpr (WPART != 0) {                             // group of the tile's first target (wave-uniform)
         const int row0 = __builtin_amdgcn_readfirstlane((int)trow[0]);
         g_first = row0 >= 0 ? a.tgt_group[DNP_BND(row0, n_tgt_group, kBndTgtGroup)] : -2;
     }
@@ -1031,51 +1065,58 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
                     vv[c] = excluded ? PT(0) : v;
                     o[c] = vv[c];
                 }
-                if constexpr (WPART && MODE == kField) {
+                if constexpr (WPART != 0 && MODE == kField) {
                     // per-point dot in fp32 like (E[patch] * pts[patch, 3:]).sum(dim=-1) (field_utils.py:316), patch sums in fp64
                     // (products rounded separately, added left to right - no fma contraction: W from this epilogue, W from
                     // interactions_kernel and torch's elementwise product + sum must not depend on a compiler's choice)
+                    // (F = double, the fp64 drivers of round 5: the dot in fp64, as the reference's on a float64 cloud)
                     const F* n = a.tgt + trow[k] * a.ld_tgt + 3;
-                    float d;
+                    F d;
                     {
 #pragma clang fp contract(off)
-                        d = ((float)vv[0] * n[0] + (float)vv[1] * n[1]) + (float)vv[2] * n[2];
+                        d = ((F)vv[0] * n[0] + (F)vv[1] * n[1]) + (F)vv[2] * n[2];
                     }
-                    if (grp == g_first) w_first += (double)d; else w_other += (double)d;
+                    if constexpr (WPART == 3) {
+                        if (grp == g_first) w_first += (double)d; else if (grp == g_first + 1) w_second += (double)d; else w_other += (double)d;
+                    } else {
+                        if (grp == g_first) w_first += (double)d; else w_other += (double)d;
+                    }
                 }
             }
         }
     }
-#ifdef DNP_BOUNDS    // WPART's precondition: the tile's rows take at most two group values (else w_other mixes patches)
-    if constexpr (WPART && MODE == kField) {
+#ifdef DNP_BOUNDS    // WPART's precondition: the tile's rows take at most WPART group values (else w_other mixes patches)
+    if constexpr (WPART != 0 && MODE == kField) {
+        auto named = [&](int64_t gq) { return gq == g_first || (WPART == 3 && gq == g_first + 1); };
         int64_t other = -9;
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
             const int64_t t = tile_base + (int64_t)tg * (64 * KT) + k * 64 + (tid & 63);
-            if (t < a.T) { const int64_t gq = a.tgt_group[DNP_BND(trow[k], n_tgt_group, kBndTgtGroup)]; if (gq != g_first) other = gq; }
+            if (t < a.T) { const int64_t gq = a.tgt_group[DNP_BND(trow[k], n_tgt_group, kBndTgtGroup)]; if (!named(gq)) other = gq; }
         }
         const int64_t omax = wave_max<int64_t>(other);
         bool bad = false;
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
             const int64_t t = tile_base + (int64_t)tg * (64 * KT) + k * 64 + (tid & 63);
-            if (t < a.T) { const int64_t gq = a.tgt_group[DNP_BND(trow[k], n_tgt_group, kBndTgtGroup)]; bad |= (gq != g_first && gq != omax); }
+            if (t < a.T) { const int64_t gq = a.tgt_group[DNP_BND(trow[k], n_tgt_group, kBndTgtGroup)]; bad |= (!named(gq) && gq != omax); }
         }
         if (__any(bad) && (tid & 63) == 0 && a.bnd.err) atomicAdd(a.bnd.err + kBndGroups, 1u);   // the CALLER's error, not an access
     }
 #endif
-    if constexpr (WPART && MODE == kField) {
+    if constexpr (WPART != 0 && MODE == kField) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {             // fixed butterfly: the sums do not depend on anything but the tile
             w_first += __shfl_xor(w_first, off, 64);
             w_other += __shfl_xor(w_other, off, 64);
+            if constexpr (WPART == 3) w_second += __shfl_xor(w_second, off, 64);
         }
         const int64_t n_tiles = (a.T + 64 * KT - 1) / (64 * KT);
         const int64_t wave_tile = (int64_t)bx * ktg + tg;
         if ((tid & 63) == 0 && wave_tile < n_tiles) {
-            double* wp = a.w_part + DNP_BND(((int64_t)chunk * n_tiles + wave_tile) * 2, n_w_part - 1, kBndWPart);
+            double* wp = a.w_part + DNP_BND(((int64_t)chunk * n_tiles + wave_tile) * WPART, n_w_part - (WPART - 1), kBndWPart);
             wp[0] = w_first;
-            wp[1] = w_other;
+            if constexpr (WPART == 3) { wp[1] = w_second; wp[2] = w_other; } else { wp[1] = w_other; }
         }
     }
     DNP_STAMP_END();

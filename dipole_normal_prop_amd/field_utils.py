@@ -7,8 +7,10 @@ fallback: without the library or without a HIP device these functions raise.
 
 Device convention: tensors may live on the CPU or on a HIP device.  CPU tensors are staged to
 the current device for the call and the result comes back on the CPU, so `out.device ==
-in.device` as in the reference.  fp32 and fp64 are supported (the reference's socket path feeds
-fp64, util.py:71-77); other dtypes are computed in fp32 and cast back.
+in.device` as in the reference.  fp32 and fp64 are supported: a float64 cloud is computed in float64 by EVERY entry point, as the
+reference computes in the dtype it is handed (its socket path feeds fp64, util.py:71-77) - the field kernels, the
+per-point, patch and representative drivers, the sharded driver and the xie ordered propagation; other dtypes are
+computed in fp32 and cast back.
 
 Reference lines each function mirrors are cited in its docstring.
 """
@@ -584,11 +586,21 @@ def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, ep
                  w_part: Optional[torch.Tensor] = None, source_split: int = 1) -> torch.Tensor:
     """dE[p1 - p0, N, 3]: the fields of patches p0..p1 on every point (dnp_patch_fields_tiled_f32).  boxes / tile_boxes:
     the per-cloud box tables of the far-field test (_patch_boxes, _tile_boxes); w_part: receives the per-tile
-    interaction partials (see _TileTables).  source_split = -k: the last k patches of the launch as split items whose run
+    interaction partials [p1 - p0, n_tiles, 2 or 3] (see _TileTables; the last dimension = the group slots per tile).
+    source_split = -k: the last k patches of the launch as split items whose run
     terms travel through the exchange buffer (needs both box tables; without them the launch is the plain one)."""
     lib = _lib.require_device()
     N = work.shape[0]
-    dE = torch.empty((p1 - p0, N, 3), dtype=torch.float32, device=work.device)
+    dE = torch.empty((p1 - p0, N, 3), dtype=work.dtype, device=work.device)
+    if work.dtype == torch.float64:
+        # a float64 cloud: double-precision slabs (no far-field chain in this precision: no box tables, no split tail)
+        with _on_device(work.device):
+            rc = lib.dnp_patch_fields_tiled_f64(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
+                                                off.shape[0] - 1, _lib.ptr(point_patch), p0, p1, float(eps), _lib.ptr(dE),
+                                                _lib.ptr(w_part), 2 if w_part is None else int(w_part.shape[-1]),
+                                                _lib.current_stream())
+        _lib.check(rc)
+        return dE
     xch, xch_bytes = None, 0
     if source_split < 0 and boxes is not None and tile_boxes is not None:
         xch_bytes = int(lib.dnp_patch_exchange_bytes(N, min(-source_split, p1 - p0)))
@@ -596,24 +608,39 @@ def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, ep
     with _on_device(work.device):
         rc = lib.dnp_patch_fields_tiled_f32(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
                                             off.shape[0] - 1, _lib.ptr(point_patch), _lib.ptr(boxes), _lib.ptr(tile_boxes),
-                                            p0, p1, float(eps), _lib.ptr(dE), _lib.ptr(w_part), int(source_split),
+                                            p0, p1, float(eps), _lib.ptr(dE), _lib.ptr(w_part),
+                                            2 if w_part is None else int(w_part.shape[-1]), int(source_split),
                                             _lib.ptr(xch), xch_bytes, _lib.current_stream())
     _lib.check(rc)
     return dE
 
 
-def _tiles_within_two_groups(sizes, n_rows: int, rows_per_tile: int) -> bool:
-    """Does every tile of `rows_per_tile` consecutive rows of the patch-sorted cloud lie inside at most two groups
-    (group = a patch; the rows behind the last patch form one more group)?  From the patch sizes alone (host, no sync):
-    the group index of a tile's last row minus that of its first must be <= 1 (an empty patch in between makes the
-    index jump by two: refused, conservatively)."""
+def _tile_group_slots(sizes, n_rows: int, rows_per_tile: int) -> int:
+    """How many group slots per tile the pair kernel's interaction partials need on this patch-sorted cloud: 2 when every
+    tile of `rows_per_tile` consecutive rows lies inside at most two groups (group = a patch; the rows behind the last patch
+    form one more group), 3 when inside at most three CONSECUTIVE groups (round 5: patches of 64..127 points - the reference's
+    grid partitions start at 100), 0 when neither (then W comes from the K3 pass over the slabs).  From the patch sizes alone
+    (host, no sync): the group index of a tile's last row minus that of its first must be <= slots - 1; an empty patch
+    between two patches of a tile makes the index jump and is refused, conservatively."""
     n_tiles = -(-n_rows // rows_per_tile)
     if n_tiles == 0:
-        return True
-    ends = np.cumsum(np.asarray(sizes, dtype=np.int64))
+        return 2
+    sizes = np.asarray(sizes, dtype=np.int64)
+    ends = np.cumsum(sizes)
     first = np.arange(n_tiles, dtype=np.int64) * rows_per_tile
     last = np.minimum(first + rows_per_tile, n_rows) - 1
-    return bool(np.all(np.searchsorted(ends, last, side="right") - np.searchsorted(ends, first, side="right") <= 1))
+    span = np.searchsorted(ends, last, side="right") - np.searchsorted(ends, first, side="right")
+    worst = int(span.max())
+    if worst <= 1:
+        return 2
+    if worst == 2 and not bool(np.any(sizes == 0)):
+        return 3
+    return 0
+
+
+def _tiles_within_two_groups(sizes, n_rows: int, rows_per_tile: int) -> bool:
+    """Does every tile lie inside at most two groups (the 2-slot form of the interaction partials)?"""
+    return _tile_group_slots(sizes, n_rows, rows_per_tile) == 2
 
 
 class _TileTables:
@@ -621,18 +648,21 @@ class _TileTables:
     (tile i = sorted rows [i R, (i+1) R), R = dnp_patch_tile_rows() = the 128 targets one wavefront owns) and whether
     every tile lies inside at most two groups (patches; rows in no patch form the last group) - then the kernel's
     epilogue can leave the interaction sums per (slab, tile, group slot) and W needs no second pass over the slabs."""
-    __slots__ = ("rows", "n_tiles", "boxes", "fused")
+    __slots__ = ("rows", "n_tiles", "boxes", "fused", "slots")
 
     def __init__(self, swork: torch.Tensor, sizes: np.ndarray):
         lib = _lib.require_device()
         N = swork.shape[0]
         self.rows = int(lib.dnp_patch_tile_rows())
         self.n_tiles = -(-N // self.rows)
-        self.boxes = torch.empty((self.n_tiles, 6), dtype=torch.float32, device=swork.device)
-        with _on_device(swork.device):
-            _lib.check(lib.dnp_tile_boxes_f32(_lib.ptr(swork), N, swork.stride(0), self.rows, _lib.ptr(self.boxes),
-                                              _lib.current_stream()))
-        self.fused = _tiles_within_two_groups(sizes, N, self.rows)
+        self.boxes = None                                   # float64 clouds run without the far-field chain: no box table
+        if swork.dtype == torch.float32:
+            self.boxes = torch.empty((self.n_tiles, 6), dtype=torch.float32, device=swork.device)
+            with _on_device(swork.device):
+                _lib.check(lib.dnp_tile_boxes_f32(_lib.ptr(swork), N, swork.stride(0), self.rows, _lib.ptr(self.boxes),
+                                                  _lib.current_stream()))
+        self.slots = _tile_group_slots(sizes, N, self.rows)        # 2 / 3 group slots per tile, 0 = not fusable
+        self.fused = self.slots != 0
 
 
 # Split tail of the pair kernel's launches (include/dnp.h, dnp_patch_fields_tiled_f32).  A launch ends with ~50 us of a
@@ -662,15 +692,16 @@ def _slabs_and_rows(swork, off, point_patch, b0: int, b1: int, eps: float, boxes
     tiles allow it the interaction rows come out of the pair kernel's epilogue (+ a tiny gather kernel), otherwise from
     the K3 pass over the slabs."""
     P = off.shape[0] - 1
-    split = 1 if (sizes is None or tiles is None or boxes is None) else _pick_source_split(np.asarray(sizes)[b0:b1], swork.shape[0])
-    if tiles is not None and tiles.fused and boxes is not None and eps >= 1e-30:
+    f64 = swork.dtype == torch.float64
+    split = 1 if (sizes is None or tiles is None or boxes is None or f64) else _pick_source_split(np.asarray(sizes)[b0:b1], swork.shape[0])
+    if tiles is not None and tiles.fused and ((boxes is not None and eps >= 1e-30) or (f64 and eps > 0)):
         lib = _lib.require_device()
         K, N = b1 - b0, swork.shape[0]
-        w_part = torch.empty((K, tiles.n_tiles, 2), dtype=torch.float64, device=swork.device)
+        w_part = torch.empty((K, tiles.n_tiles, tiles.slots), dtype=torch.float64, device=swork.device)
         dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, tiles.boxes, w_part, split)
-        W = torch.empty((K, P), dtype=torch.float64, device=swork.device)
+        W = torch.empty((K, P), dtype=torch.float64, device=swork.device)            # (tile geometry and sums: the same in both precisions)
         with _on_device(swork.device):
-            _lib.check(lib.dnp_interactions_from_tiles(_lib.ptr(w_part), K, N, _lib.ptr(point_patch), _lib.ptr(off), P,
+            _lib.check(lib.dnp_interactions_from_tiles(_lib.ptr(w_part), tiles.slots, K, N, _lib.ptr(point_patch), _lib.ptr(off), P,
                                                        _lib.ptr(W), _lib.current_stream()))
         return dE, W
     dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, None if tiles is None else tiles.boxes, None, split)
@@ -682,9 +713,10 @@ def _interaction_rows(dE, work, off, idx) -> torch.Tensor:
     K, N = dE.shape[0], dE.shape[1]
     P = off.shape[0] - 1
     W = torch.empty((K, P), dtype=torch.float64, device=work.device)
+    fn = lib.dnp_interactions_f64 if dE.dtype == torch.float64 else lib.dnp_interactions_f32
     with _on_device(work.device):
-        rc = lib.dnp_interactions_f32(_lib.ptr(dE), K, N, _lib.ptr(work), work.stride(0), _lib.ptr(off),
-                                      _lib.ptr(idx), P, _lib.ptr(W), _lib.current_stream())
+        rc = fn(_lib.ptr(dE), K, N, _lib.ptr(work), work.stride(0), _lib.ptr(off), _lib.ptr(idx), P, _lib.ptr(W),
+                _lib.current_stream())
     _lib.check(rc)
     return W
 
@@ -700,12 +732,13 @@ def _combine(dE, coef: torch.Tensor, slab: torch.Tensor, E: torch.Tensor, accumu
 
 
 def _combine_signed(dE, sigma: torch.Tensor, p_lo: int, E64: torch.Tensor, accumulate: bool):
-    """E64 (+)= sum_k sigma[p_lo + k] dE[k], accumulated in fp64 (dnp_combine_signed_f32)."""
+    """E64 (+)= sum_k sigma[p_lo + k] dE[k], accumulated in fp64 (dnp_combine_signed_f32 / _f64 by the slabs' precision)."""
     lib = _lib.require_device()
     K, N = dE.shape[0], dE.shape[1]
+    fn = lib.dnp_combine_signed_f64 if dE.dtype == torch.float64 else lib.dnp_combine_signed_f32
     with _on_device(E64.device):
-        rc = lib.dnp_combine_signed_f32(_lib.ptr(dE), K, N, _lib.ptr(sigma), sigma.shape[0], int(p_lo), _lib.ptr(E64),
-                                        int(accumulate), _lib.current_stream())
+        rc = fn(_lib.ptr(dE), K, N, _lib.ptr(sigma), sigma.shape[0], int(p_lo), _lib.ptr(E64), int(accumulate),
+                _lib.current_stream())
     _lib.check(rc)
 
 
@@ -794,13 +827,13 @@ def _finish_batched(pts: torch.Tensor, st: "_Batched", diffuse: bool, listed_pat
     dev = st.swork.device
     N = st.swork.shape[0]
     direct = pts.is_cuda and pts.device == dev and pts.dtype in (torch.float32, torch.float64) and pts.stride(1) == 1
-    out = pts if direct else torch.empty((N, 6), dtype=torch.float32, device=dev)
+    out = pts if direct else torch.empty((N, 6), dtype=st.swork.dtype, device=dev)
     w_sorted = None if w is None else w[st.perm].contiguous()
+    fn = lib.dnp_patch_finish_f64 if st.swork.dtype == torch.float64 else lib.dnp_patch_finish_f32
     with _on_device(dev):
-        rc = lib.dnp_patch_finish_f32(_lib.ptr(st.swork), st.swork.stride(0), N, _lib.ptr(st.sorted_patch),
-                                      _lib.ptr(st.sigma), _lib.ptr(st.Es if diffuse else None), _lib.ptr(listed_patches),
-                                      _lib.ptr(w_sorted), _lib.ptr(st.perm), _lib.ptr(out), out.stride(0),
-                                      int(out.dtype == torch.float64), _lib.current_stream())
+        rc = fn(_lib.ptr(st.swork), st.swork.stride(0), N, _lib.ptr(st.sorted_patch), _lib.ptr(st.sigma),
+                _lib.ptr(st.Es if diffuse else None), _lib.ptr(listed_patches), _lib.ptr(w_sorted), _lib.ptr(st.perm),
+                _lib.ptr(out), out.stride(0), int(out.dtype == torch.float64), _lib.current_stream())
     _lib.check(rc)
     if not direct:
         _store_normals(pts, out[:, 3:])
@@ -825,10 +858,12 @@ class _BatchedWork:
 
 
 def _batched_begin(work: torch.Tensor, patches, diffuse: bool, eps: float = 1e-5, want_E: bool = True,
-                   rank: int = 0, world: int = 1) -> "_BatchedWork":
+                   rank: int = 0, world: int = 1, subset: bool = False) -> "_BatchedWork":
     """First half of the batched drivers on a device cloud `work[N,6]` (normals already weight-scaled): the patch-sorted
     layout, the box tables, this rank's slabs and its rows of W - everything that does not need the other ranks.  No host
-    synchronisation; the second half is _batched_end."""
+    synchronisation; the second half is _batched_end.  subset = True: the propagation runs on the LISTED points only (the
+    representatives driver: targets are representatives) - the sorted cloud has one row per listed point, perm maps it to the
+    row of `work`, and points in no patch take no part (the caller guarantees disjoint lists)."""
     dev = work.device
     N = work.shape[0]
     off, idx, sizes = util.patch_csr(patches, dev)
@@ -836,15 +871,18 @@ def _batched_begin(work: torch.Tensor, patches, diffuse: bool, eps: float = 1e-5
     # data layout for the kernels: the cloud sorted by patch (points in no patch last), so that a patch
     # is a contiguous row range - sources stream linearly and K3 reads its slab rows coalesced
     covered = int(sizes.sum())
-    if covered == N and work.is_cuda and work.dtype == torch.float32:
+    if subset:
+        N = covered
+    if covered == N and work.is_cuda and work.dtype in (torch.float32, torch.float64):
         # every point is in a patch (the callers' case): one launch builds the sorted cloud and its patch ids
         perm = idx
-        swork = torch.empty((N, 6), dtype=torch.float32, device=dev)
+        swork = torch.empty((N, 6), dtype=work.dtype, device=dev)
         point_patch = torch.empty(N, dtype=torch.int64, device=dev)
+        lib = _lib.require_device()
+        layout = lib.dnp_patch_layout_f64 if work.dtype == torch.float64 else lib.dnp_patch_layout_f32
         with _on_device(dev):
-            _lib.check(_lib.require_device().dnp_patch_layout_f32(_lib.ptr(work), work.stride(0), _lib.ptr(off),
-                                                                   _lib.ptr(idx), P, _lib.ptr(swork), _lib.ptr(point_patch),
-                                                                   _lib.current_stream()))
+            _lib.check(layout(_lib.ptr(work), work.stride(0), _lib.ptr(off), _lib.ptr(idx), P, _lib.ptr(swork),
+                              _lib.ptr(point_patch), _lib.current_stream()))
     else:
         point_patch = torch.repeat_interleave(torch.arange(P, device=dev), util.to_device(sizes, dev),
                                               output_size=covered)
@@ -866,9 +904,9 @@ def _batched_begin(work: torch.Tensor, patches, diffuse: bool, eps: float = 1e-5
     # are evaluated by one launch and kept for the diffuse combine.  Beyond it the budget is raised to 80 % of what
     # the device has free (288 GB of HBM on an MI355X), the patches go through in blocks of at most SLAB_BLOCK_BYTES,
     # as many blocks as fit are kept, and only the others are evaluated a second time for the combine.
-    boxes = _patch_boxes(swork, off, None)               # for the far-field test of the pair kernel
+    boxes = _patch_boxes(swork, off, None) if swork.dtype == torch.float32 else None   # far-field test of the fp32 pair kernel
     tiles = _TileTables(swork, sizes)                    # target-tile boxes; can W come out of the kernel's epilogue?
-    per_slab = N * 3 * 4
+    per_slab = N * 3 * swork.element_size()
     n_local = max(p_hi - p_lo, 1)
     budget = SLAB_BUDGET_BYTES
     if n_local * per_slab > SLAB_FREE_CHECK_BYTES:
@@ -930,7 +968,7 @@ def _batched_end(bw: "_BatchedWork", W_full: torch.Tensor, start_t: torch.Tensor
 
 
 def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tensor, diffuse: bool,
-                               eps: float = 1e-5, want_E: bool = True, shard=None):
+                               eps: float = 1e-5, want_E: bool = True, shard=None, subset: bool = False):
     """Core of the batched drivers on a device cloud `work[N,6]` (normals already weight-scaled); everything
     stays on the device - no host synchronisation between the launches.
 
@@ -941,7 +979,7 @@ def _batched_patch_propagation(work: torch.Tensor, patches, start_t: torch.Tenso
     `shard` = (rank, world, gather_fn): patches are split over ranks in contiguous size-balanced blocks, each
     rank computes its slabs and W rows, gather_fn(rows, bounds) returns the full W on every rank."""
     rank, world, gather = (0, 1, None) if shard is None else shard
-    bw = _batched_begin(work, patches, diffuse, eps, want_E, rank, world)
+    bw = _batched_begin(work, patches, diffuse, eps, want_E, rank, world, subset)
     W_full = bw.W_local if gather is None else gather(bw.W_local, bw.bounds)
     return _batched_end(bw, W_full, start_t)
 
@@ -976,7 +1014,7 @@ def _sequential_patch_propagation(work, patches: List[torch.Tensor], start: int,
     dev = work.device
     N, P = work.shape[0], len(patches)
     pidx = [p.to(device=dev, dtype=torch.int64) for p in patches]
-    E = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+    E = torch.zeros((N, 3), dtype=work.dtype, device=dev)
     oriented = torch.zeros(N, dtype=torch.bool, device=dev)
     all_rows = torch.arange(N, device=dev)
 
@@ -1033,14 +1071,17 @@ def _store_normals(pts: torch.Tensor, normals: torch.Tensor) -> None:
 
 
 def _prepare_work(pts: torch.Tensor, weights):
-    """Device fp32 working copy of pts (normals scaled by clamp(weights, 0.1, 1))."""
+    """Device working copy of pts (normals scaled by clamp(weights, 0.1, 1)) in the precision the propagation runs in: float64
+    for a float64 cloud - the reference's drivers compute in pts.dtype (field_utils.py:286-348, :207-282; rounds 1-4 narrowed
+    such a cloud to fp32 silently) -, float32 for everything else."""
     dev = pts.device if pts.is_cuda else _compute_device()
-    work = pts.detach().to(device=dev, dtype=torch.float32).contiguous()
+    wd = torch.float64 if pts.dtype == torch.float64 else torch.float32
+    work = pts.detach().to(device=dev, dtype=wd).contiguous()
     if work.data_ptr() == pts.data_ptr():
         work = work.clone()
     w = None
     if weights is not None:
-        w = weights.detach().to(device=dev, dtype=torch.float32).clamp(0.1, 1)
+        w = weights.detach().to(device=dev, dtype=wd).clamp(0.1, 1)
         work[:, 3:] = work[:, 3:] * w[:, None]
     return work, w
 
@@ -1076,15 +1117,15 @@ def strongest_field_propagation(pts, patches, all_patches, diffuse=False, weight
             if not diffuse or listed is not None:
                 _finish_batched(pts, st, diffuse, listed, w)
             else:                                       # diffuse lists that are not the patches themselves
-                flip = torch.where(st.point_patch >= 0, st.sigma[st.point_patch.clamp(min=0)], 1.0).to(torch.float32)
+                flip = torch.where(st.point_patch >= 0, st.sigma[st.point_patch.clamp(min=0)], 1.0).to(work.dtype)
                 work[:, 3:] = work[:, 3:] * flip[:, None]
-                _diffuse_sign_pass(work, st.field().to(torch.float32), [patch for _, patch in patches])
+                _diffuse_sign_pass(work, st.field().to(work.dtype), [patch for _, patch in patches])
                 _finish_patch_driver(pts, work, w)
             _set_trace("patches", order=st.order, sigma=st.sigma, chosen=st.chosen, start=start_t)
             return
         order, sigma, chosen, E = _sequential_patch_propagation(work, list(all_patches), int(start_t.item()), diffuse)
         if diffuse:
-            _diffuse_sign_pass(work, E.to(torch.float32), [patch for _, patch in patches])
+            _diffuse_sign_pass(work, E, [patch for _, patch in patches])
         _finish_patch_driver(pts, work, w)
         _set_trace("patches", order=order, sigma=sigma, chosen=chosen, start=start_t)
 
@@ -1109,20 +1150,51 @@ def strongest_field_propagation_reps(input_pc, reps, diffuse=False, weights=None
             rep_csr = util.patch_csr([r for r, _ in reps], dev)
             rest_csr = util.patch_csr([r for _, r in reps], dev)
         _, all_reps, rep_sizes = rep_csr
-        rep_pid, rest_pid = _listing_ids(rep_csr), _listing_ids(rest_csr)      # every host->device copy happens here,
-        rep_lists = util.PatchList(all_reps, rep_sizes)                        # before the long kernels are enqueued
+        rep_lists = util.PatchList(all_reps, rep_sizes)
         start_t = _start_tensor(work, rep_lists, start_patch)
         mode = PATCH_MODE
         if mode == "auto":
             mode = "batched" if known_disjoint or _disjoint(all_reps, N) else "sequential"
-        # the loop's targets are representatives only: run it on the compact sub-cloud of the representatives
-        # (patch k = the contiguous row range of its representatives) and scatter back
-        sub = work[all_reps].contiguous()
-        sub_patches = util.PatchList(torch.arange(all_reps.shape[0], device=dev), rep_sizes)
         n_rest = int(rest_csr[2].sum())
         # representatives and rests partition the cloud (what the callers pass): every point is listed exactly once
         partition = known_disjoint and isinstance(reps, util.RepLists) and reps.rests.disjoint \
             and int(rep_sizes.sum()) + n_rest == N
+        if mode == "batched" and partition and work.is_cuda:
+            # The callers' case, everything in the library's kernels (round 5; rounds 2-4 ran ~40 small torch launches around
+            # the pair kernel here - profiles/r05_config3_kernels.txt).  The loop's targets are representatives only: the
+            # sorted cloud of the propagation is built straight from `work` through the representatives' index list
+            # (subset), the fused tail stores their oriented normals back into `work`, the field of ALL representatives
+            # (sources in point order, as the reference sums them: field_grad(pts[oriented_pts_mask], ...)) is evaluated at
+            # the rest points, and one launch gives every rest point its patch's flip and the sign of that field.
+            lib = _lib.require_device()
+            f64 = work.dtype == torch.float64
+            st = _batched_patch_propagation(work, rep_lists, start_t, diffuse, subset=True)
+            order, sigma, chosen = st.order, st.sigma, st.chosen
+            with _on_device(dev):
+                rc = (lib.dnp_patch_finish_f64 if f64 else lib.dnp_patch_finish_f32)(
+                    _lib.ptr(st.swork), st.swork.stride(0), st.swork.shape[0], _lib.ptr(st.sorted_patch), _lib.ptr(st.sigma),
+                    _lib.ptr(st.Es if diffuse else None), None, None, _lib.ptr(st.perm), _lib.ptr(work), work.stride(0),
+                    int(f64), _lib.current_stream())
+            _lib.check(rc)
+            if n_rest:
+                rest = rest_csr[1]                                # targets are independent rows: their order is free
+                # sources as a compact copy in point order: contiguous rows go through the scalar-unit kernel
+                src = work[reps.sorted_reps(dev)].contiguous()
+                E2 = torch.empty((n_rest, 3), dtype=work.dtype, device=dev)
+                _pairs_into("field", src, None, work, rest, 1e-5, 15000, E2)
+                with _on_device(dev):
+                    rc = (lib.dnp_rest_finish_f64 if f64 else lib.dnp_rest_finish_f32)(
+                        _lib.ptr(work), work.stride(0), _lib.ptr(rest_csr[0]), _lib.ptr(rest), len(rest_csr[2]),
+                        _lib.ptr(sigma), _lib.ptr(E2), _lib.current_stream())
+                _lib.check(rc)
+            _finish_patch_driver(input_pc, work, w)
+            _set_trace("reps", order=order, sigma=sigma, chosen=chosen, start=start_t)
+            return
+        # ---- general lists (overlapping, not a partition, or the step-by-step mode): the loop runs on the compact sub-cloud
+        # of the representatives (patch k = the contiguous row range of its representatives), the rest in torch
+        rep_pid, rest_pid = _listing_ids(rep_csr), _listing_ids(rest_csr)
+        sub = work[all_reps].contiguous()
+        sub_patches = util.PatchList(torch.arange(all_reps.shape[0], device=dev), rep_sizes)
         if mode == "batched":
             st = _batched_patch_propagation(sub, sub_patches, start_t, diffuse)
             order, sigma, chosen = st.order, st.sigma, st.chosen
@@ -1131,48 +1203,28 @@ def strongest_field_propagation_reps(input_pc, reps, diffuse=False, weights=None
             order, sigma, chosen, E_sub = _sequential_patch_propagation(sub, list(sub_patches), int(start_t.item()),
                                                                         diffuse)
             neg = torch.from_numpy(sigma < 0).to(dev)
-        if mode == "batched" and partition:
-            # patch flips and the diffuse sign pass of the representatives in ONE launch (the patch drivers' fused
-            # tail on the sub-cloud, stored straight into the working cloud), then the rests' flips
-            lib = _lib.require_device()
-            to_point = all_reps[st.perm]                                   # sorted sub-cloud row -> point
-            with _on_device(dev):
-                rc = lib.dnp_patch_finish_f32(_lib.ptr(st.swork), st.swork.stride(0), st.swork.shape[0],
-                                              _lib.ptr(st.sorted_patch), _lib.ptr(st.sigma),
-                                              _lib.ptr(st.Es if diffuse else None), None, None, _lib.ptr(to_point),
-                                              _lib.ptr(work), work.stride(0), 0, _lib.current_stream())
-            _lib.check(rc)
-            _flip_by_listing(work, neg, rest_csr[1], rest_pid)
+        E = torch.zeros((N, 3), dtype=work.dtype, device=dev)
+        if mode == "batched":
+            if st.Es is not None:
+                E[all_reps] = st.field().to(work.dtype)
         else:
-            E = torch.zeros((N, 3), dtype=torch.float32, device=dev)
-            if mode == "batched":
-                if st.Es is not None:
-                    E[all_reps] = st.field().to(torch.float32)
-            else:
-                E[all_reps] = E_sub
-            _flip_by_listing(work, neg, all_reps, rep_pid)
-            _flip_by_listing(work, neg, rest_csr[1], rest_pid)
-            if diffuse:
-                _diffuse_sign_pass(work, E, rep_lists)
+            E[all_reps] = E_sub
+        _flip_by_listing(work, neg, all_reps, rep_pid)
+        _flip_by_listing(work, neg, rest_csr[1], rest_pid)
+        if diffuse:
+            _diffuse_sign_pass(work, E, rep_lists)
         # every non-representative point: sign of the field of all representatives
         # (field_grad(pts[oriented_pts_mask], pts[~oriented_pts_mask]): both sides in point order)
-        if partition:
-            # no mask, no host round trip
-            rest = rest_csr[1] if n_rest else None            # targets are independent rows: their order is free
-            src_rows = reps.sorted_reps(dev)                  # sources in point order, as the reference sums them
-        else:
-            is_rep = torch.zeros(N, dtype=torch.bool, device=dev)
-            is_rep[all_reps] = True
-            rest = torch.nonzero(~is_rep).flatten()
-            rest = rest if rest.numel() else None
-            src_rows = torch.nonzero(is_rep).flatten()
+        is_rep = torch.zeros(N, dtype=torch.bool, device=dev)
+        is_rep[all_reps] = True
+        rest = torch.nonzero(~is_rep).flatten()
+        rest = rest if rest.numel() else None
+        src_rows = torch.nonzero(is_rep).flatten()
         if rest is not None:
-            # sources as a compact copy: contiguous rows go through the scalar-unit kernel, a row gather would
-            # need the LDS one
             src = work[src_rows].contiguous()
-            E2 = torch.empty((rest.shape[0], 3), dtype=torch.float32, device=dev)
+            E2 = torch.empty((rest.shape[0], 3), dtype=work.dtype, device=dev)
             _pairs_into("field", src, None, work, rest, 1e-5, 15000, E2)
-            s = ((E2 * work[rest, 3:]).sum(dim=-1) > 0).float() * 2 - 1
+            s = ((E2 * work[rest, 3:]).sum(dim=-1) > 0).to(work.dtype) * 2 - 1
             work[rest, 3:] = work[rest, 3:] * s[:, None]
         _finish_patch_driver(input_pc, work, w)
         _set_trace("reps", order=order, sigma=sigma, chosen=chosen, start=start_t)
@@ -1335,18 +1387,28 @@ def xie_propagation_points_in_order(pts: torch.Tensor, eps, order, diffuse=False
     lib = _lib.require_device()
     with torch.no_grad():
         dev = pts.device if pts.is_cuda else _compute_device()
-        work = pts.detach().to(device=dev, dtype=torch.float32).contiguous()
+        # the reference computes in pts.dtype (interactions / weights are created with .type(pts.dtype), :581-586): a float64
+        # cloud (its socket path, socket_server_para.py:68-83) gets a float64 matrix and float64 row sums
+        wd = torch.float64 if pts.dtype == torch.float64 else torch.float32
+        work = pts.detach().to(device=dev, dtype=wd).contiguous()
         order_t = torch.as_tensor(np.asarray(order)).to(device=dev, dtype=torch.int64).contiguous()
         T, N = order_t.shape
-        M = xie_intersaction(work, work, eps, knn_mask, C).to(torch.float32).contiguous()     # [N, N]
-        weights = torch.empty((T, N), dtype=torch.float32, device=dev)
-        inter = torch.empty((T, N), dtype=torch.float32, device=dev)
+        M = xie_intersaction(work, work, eps, knn_mask, C).to(wd).contiguous()     # [N, N]
+        # no initialisation needed: the kernels zero `inter` themselves (an order row that repeats an index leaves points
+        # unvisited, and the reference's interactions start as torch.zeros) and write every weight
+        weights = torch.empty((T, N), dtype=wd, device=dev)
+        inter = torch.empty((T, N), dtype=wd, device=dev)
+        f64 = wd == torch.float64
         with _on_device(dev):
-            rc = lib.dnp_xie_order_f32(_lib.ptr(M), N, _lib.ptr(order_t), T, _lib.ptr(weights), _lib.ptr(inter),
-                                       _lib.current_stream())
+            rc = (lib.dnp_xie_order_f64 if f64 else lib.dnp_xie_order_f32)(_lib.ptr(M), N, _lib.ptr(order_t), T, _lib.ptr(weights),
+                                                                          _lib.ptr(inter), _lib.current_stream())
         _lib.check(rc)
         if diffuse:
-            inter = weights @ M.transpose(0, 1)            # interactions[t][i] = sum_j M[i][j] * w[t][j]
+            # interactions[t][i] = sum_j M[i][j] * w[t][j] (:597-603): one pass over M for all T weight vectors
+            with _on_device(dev):
+                rc = (lib.dnp_xie_rowdots_f64 if f64 else lib.dnp_xie_rowdots_f32)(_lib.ptr(M), N, _lib.ptr(weights), T,
+                                                                                  _lib.ptr(inter), _lib.current_stream())
+            _lib.check(rc)
         return (inter < 0).to(pts.device)
 
 

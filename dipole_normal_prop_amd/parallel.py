@@ -115,9 +115,9 @@ def _finish_sharded(fu, pts, work, w, st, patches, diffuse, listed, start_t):
     if not diffuse or listed is not None:
         fu._finish_batched(pts, st, diffuse, listed, w)
     else:
-        flip = torch.where(st.point_patch >= 0, st.sigma[st.point_patch.clamp(min=0)], 1.0).to(torch.float32)
+        flip = torch.where(st.point_patch >= 0, st.sigma[st.point_patch.clamp(min=0)], 1.0).to(work.dtype)
         work[:, 3:] = work[:, 3:] * flip[:, None]
-        fu._diffuse_sign_pass(work, st.field().to(torch.float32), [patch for _, patch in patches])
+        fu._diffuse_sign_pass(work, st.field().to(work.dtype), [patch for _, patch in patches])
         fu._finish_patch_driver(pts, work, w)
     fu._set_trace("sharded", order=st.order, sigma=st.sigma, chosen=st.chosen, start=start_t)
 

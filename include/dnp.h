@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DNP_VERSION 400 /* 0.4.0 */
+#define DNP_VERSION 500 /* 0.5.0: the fp64 patch-driver entry points, dnp_xie_order_f64, dnp_xie_rowdots_* */
 
 enum {
     DNP_OK = 0,
@@ -162,13 +162,17 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts,
  *   tile_box[ceil(N / R)][6]  boxes of the target tiles, tile i = rows [i R, (i+1) R), R = dnp_patch_tile_rows() = the 128
  *                             rows one wavefront of the kernel owns (dnp_tile_boxes_f32; NULL = the wavefront finds the
  *                             box of its targets itself, 36 cross-lane steps per (wavefront, patch)), and
- *   w_part[p_end-p_begin][ceil(N / R)][2]  (optional, NULL = not wanted) the interaction sums of every tile:
- *       w_part[k][i][0] = sum_{t in tile i, patch(t) == patch(first row of tile i)} dE[k][t] . n_t
- *       w_part[k][i][1] = the same over the tile's other rows
+ *   w_part[p_end-p_begin][ceil(N / R)][w_slots]  (optional, NULL = not wanted; w_slots = 2 or 3) the interaction sums of
+ *     every tile:
+ *       w_part[k][i][0] = sum_{t in tile i, patch(t) == g} dE[k][t] . n_t,  g = the patch of the tile's first row
+ *       w_slots = 2:  w_part[k][i][1] = the same over the tile's other rows
+ *       w_slots = 3:  w_part[k][i][1] = over the rows of patch g + 1,  w_part[k][i][2] = over the remaining rows
  *     (fp32 dot per point as the reference's (E[patch] * pts[patch, 3:]).sum(dim=-1), field_utils.py:316, fp64 sums in a
- *     fixed order).  With every tile inside at most two groups (patches of >= R points; rows in no patch last) W follows
- *     from dnp_interactions_from_tiles without a second pass over the 12 N P bytes of slabs; the caller checks that
- *     condition (the drivers do, on the host, from the patch sizes) and uses dnp_interactions_f32 otherwise.
+ *     fixed order).  With every tile inside at most w_slots groups (2: patches of >= R points; 3, round 5: patches of >= R / 2
+ *     points - the reference's own grid partitions with their 100-point minimum; rows in no patch last; no empty patch
+ *     between two patches of a tile) W follows from dnp_interactions_from_tiles without a second pass over the 12 N P bytes
+ *     of slabs; the caller checks that condition (the drivers do, on the host, from the patch sizes;
+ *     dnp_check_tile_groups does it on the device) and uses dnp_interactions_f32 otherwise.
  * source_split (1 or -k; -k needs both tables and the exchange buffer): -k (k >= 1) is ONE launch in which the LAST k patches
  * of the range (k >= the range: all of them) are evaluated as SPLIT ITEMS - four wavefronts per target tile, wavefront i
  * on the patch's i-th run of 128 sources; every run term is written to `exchange` with write-through stores, an arrival
@@ -193,8 +197,19 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts,
                                const int64_t* patch_off, const int64_t* patch_idx, int64_t P,
                                const int64_t* point_patch, const float* patch_box, const float* tile_box,
                                int64_t p_begin, int64_t p_end, float eps,
-                               float* dE, double* w_part, int source_split,
+                               float* dE, double* w_part, int w_slots, int source_split,
                                void* exchange, size_t exchange_bytes, void* stream);
+/* The same slabs for a FLOAT64 cloud (round 5).  The reference computes in the dtype it is handed (field_utils.py:96-109; its
+ * socket path hands it float64, util.py:71-77), so on a float64 cloud the greedy drivers' per-patch fields (field_utils.py:
+ * 328-331, :258-265), interaction sums (:316, :244) and diffuse field are double precision here too.  dE is [p_end - p_begin, N, 3]
+ * doubles; w_part as above (the per-point dot taken in fp64), same precondition (dnp_check_tile_groups), tiles of
+ * dnp_patch_tile_rows() rows.  No far-field chain in this precision (its truncation error is an fp32 ulp), hence no box tables
+ * and no split tail: the scalar-unit kernel on the patch-sorted layout (patch_idx == NULL, eps > 0), the LDS kernel otherwise
+ * (w_part must be NULL then).  Within ~1e-15 of the reference's float64 arithmetic per pair (refined v_rsq_f64 / v_rcp_f64). */
+int dnp_patch_fields_tiled_f64(const double* pts, int64_t N, int64_t ld_pts,
+                               const int64_t* patch_off, const int64_t* patch_idx, int64_t P,
+                               const int64_t* point_patch, int64_t p_begin, int64_t p_end, double eps,
+                               double* dE, double* w_part, int w_slots, void* stream);
 size_t dnp_patch_exchange_bytes(int64_t N, int64_t split_patches);
 int dnp_exchange_init(void* exchange, size_t bytes, void* stream);
 /* The precondition of w_part, checked on the device for callers that cannot check it from patch sizes on the host (the
@@ -202,10 +217,10 @@ int dnp_exchange_init(void* exchange, size_t bytes, void* stream);
  * number of target tiles of dnp_patch_tile_rows() rows whose rows take three or more values of point_patch.  Nonzero means
  * w_part would be wrong for those tiles - use dnp_interactions_f32 on the slabs instead.  No synchronisation: read the
  * counter behind the stream.  (A -DDNP_BOUNDS build of the library checks the same inside the pair kernel.) */
-int dnp_check_tile_groups(const int64_t* point_patch, int64_t N, int32_t* violations, void* stream);
+int dnp_check_tile_groups(const int64_t* point_patch, int64_t N, int w_slots, int32_t* violations, void* stream);
 /* W[k][j] = sum of w_part[k][i][slot] over the tiles i that overlap patch j (slot 0 when j is the patch of the tile's
  * first row), in tile order; W is [K, P] doubles.  Same quantity as dnp_interactions_f32 up to fp64 reassociation. */
-int dnp_interactions_from_tiles(const double* w_part, int64_t K, int64_t N, const int64_t* point_patch,
+int dnp_interactions_from_tiles(const double* w_part, int w_slots, int64_t K, int64_t N, const int64_t* point_patch,
                                 const int64_t* patch_off, int64_t P, double* W, void* stream);
 
 /* ---- K3: patch interaction matrix -----------------------------------------------------
@@ -216,6 +231,11 @@ int dnp_interactions_from_tiles(const double* w_part, int64_t K, int64_t N, cons
  */
 int dnp_interactions_f32(const float* dE, int64_t K, int64_t N,
                          const float* pts, int64_t ld_pts,
+                         const int64_t* patch_off, const int64_t* patch_idx, int64_t P,
+                         double* W, void* stream);
+/* float64 slabs and cloud: the per-point dot in fp64 (the reference's (E[patch] * pts[patch, 3:]).sum(dim=-1) on a float64 cloud) */
+int dnp_interactions_f64(const double* dE, int64_t K, int64_t N,
+                         const double* pts, int64_t ld_pts,
                          const int64_t* patch_off, const int64_t* patch_idx, int64_t P,
                          double* W, void* stream);
 
@@ -294,6 +314,10 @@ int dnp_patch_greedy(const double* W, int64_t P, const int64_t* start, int64_t* 
  * reference's own fp32 chain E = E + dE in visit order is dnp_combine_fields_f32). */
 int dnp_combine_signed_f32(const float* dE, int64_t K, int64_t N, const double* sigma, int64_t P, int64_t p_lo,
                            double* E, int accumulate, void* stream);
+/* the same for float64 slabs (dnp_patch_fields_tiled_f64): the reference's E = E + dE chain in the visit order differs from this
+ * slab-order sum by fp64 reassociation only (~1e-16 relative) */
+int dnp_combine_signed_f64(const double* dE, int64_t K, int64_t N, const double* sigma, int64_t P, int64_t p_lo,
+                           double* E, int accumulate, void* stream);
 
 /* ---- patch-sorted working layout  (the set-up of the batched drivers) -----------------------------------------
  *
@@ -303,6 +327,8 @@ int dnp_combine_signed_f32(const float* dE, int64_t K, int64_t N, const double* 
  */
 int dnp_patch_layout_f32(const float* pts, int64_t ld_pts, const int64_t* patch_off, const int64_t* patch_idx,
                          int64_t P, float* swork, int64_t* sorted_patch, void* stream);
+int dnp_patch_layout_f64(const double* pts, int64_t ld_pts, const int64_t* patch_off, const int64_t* patch_idx,
+                         int64_t P, double* swork, int64_t* sorted_patch, void* stream);
 
 /* ---- tail of the batched patch drivers in one launch (field_utils.py:322-323, :337-342, :344-346) ----------
  *
@@ -317,6 +343,24 @@ int dnp_patch_layout_f32(const float* pts, int64_t ld_pts, const int64_t* patch_
 int dnp_patch_finish_f32(const float* work, int64_t ld_work, int64_t N, const int64_t* point_patch,
                          const double* sigma, const double* E64, const unsigned char* listed, const float* weights,
                          const int64_t* perm, void* out, int64_t ld_out, int out_is_f64, void* stream);
+/* float64 working cloud and weights: the field is used as held (doubles), dot, sign and un-scaling in fp64 */
+int dnp_patch_finish_f64(const double* work, int64_t ld_work, int64_t N, const int64_t* point_patch,
+                         const double* sigma, const double* E64, const unsigned char* listed, const double* weights,
+                         const int64_t* perm, void* out, int64_t ld_out, int out_is_f64, void* stream);
+
+/* ---- tail of the representatives driver for the non-representative points, in one launch
+ *      (field_utils.strongest_field_propagation_reps: :251-252 a flipped patch flips its rest points, :273-276 every
+ *      non-representative point takes the sign of the field of all representatives) ----------------------------------
+ *
+ * rest_off[P+1] / rest_idx: CSR of the patches' rest points (rows of work), every point listed once; sigma[P] = +-1 from
+ * dnp_patch_greedy; E[M,3] = the field of the representatives at the rest points, row i for rest_idx[i] (dnp_field_grad_*
+ * with tgt_idx = rest_idx).  In place on work[., 3..5]:  n = n * sigma[p];  n *= (E[i] . n > 0) ? +1 : -1  (the dot's products
+ * rounded separately and added in order, as torch's (E * n).sum(dim=-1)).
+ */
+int dnp_rest_finish_f32(float* work, int64_t ld_work, const int64_t* rest_off, const int64_t* rest_idx, int64_t P,
+                        const double* sigma, const float* E, void* stream);
+int dnp_rest_finish_f64(double* work, int64_t ld_work, const int64_t* rest_off, const int64_t* rest_idx, int64_t P,
+                        const double* sigma, const double* E, void* stream);
 
 /* ---- merge of small voxel cells  (util.merge_nodes, util.py:448-492) - HOST function, host pointers ----
  *
@@ -343,7 +387,12 @@ int dnp_merge_cells(const int32_t* cell_ijk, const int64_t* cell_size, int64_t C
  * (field_utils.py:590-595) for R visiting orders over an N x N interaction matrix M (row = receiving point):
  *   for i in 0..N-1:  idx = order[r][i];  inter[r][idx] = sum_j M[idx][j] * w[r][j];
  *                     w[r][idx] = inter[r][idx] < 0 ? -1 : +1            (w starts at 0)
- * weights / inter are [R, N] float outputs.
+ * weights / inter are [R, N] outputs in M's precision (the buffers need no initialisation: entries of points an order row
+ * never visits - a row that repeats an index - come back 0, as the reference's torch.zeros).  _f64: float64 matrices (a
+ * float64 cloud, field_utils.py:581-595 computes in pts.dtype).  Products are rounded in M's precision, row sums run in fp64.
+ *
+ * dnp_xie_rowdots: the diffuse pass behind that loop (field_utils.py:597-603): out[r][i] = sum_j M[i][j] * w[r][j] for the R
+ * weight vectors in one pass over M ([R, N] in, [R, N] out; one wavefront per matrix row, HBM-bound).
  */
 int dnp_xie_pairs_f32(const float* src, int64_t S, int64_t ld_src, const float* tgt, int64_t T, int64_t ld_tgt,
                       float C, int vector_out, float* out, void* stream);
@@ -351,6 +400,10 @@ int dnp_xie_pairs_f64(const double* src, int64_t S, int64_t ld_src, const double
                       double C, int vector_out, double* out, void* stream);
 int dnp_xie_order_f32(const float* M, int64_t N, const int64_t* order, int64_t R, float* weights, float* inter,
                       void* stream);
+int dnp_xie_order_f64(const double* M, int64_t N, const int64_t* order, int64_t R, double* weights, double* inter,
+                      void* stream);
+int dnp_xie_rowdots_f32(const float* M, int64_t N, const float* weights, int64_t R, float* out, void* stream);
+int dnp_xie_rowdots_f64(const double* M, int64_t N, const double* weights, int64_t R, double* out, void* stream);
 
 /* ---- '.xyz' text  (util.export_pc util.py:46-51, util.xyz2tensor util.py:53-69) - HOST functions, host pointers ---
  *

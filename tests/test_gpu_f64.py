@@ -1,0 +1,391 @@
+"""Round 5: a float64 cloud is computed in float64 by every driver, as the reference computes in the dtype it is handed
+(field_utils.py:96-109, :286-348, :207-282, :569-605; its socket path hands it float64, util.py:71-77).  Goldens: G21 - the
+reference's own float64 runs of two G6 variants (+ one more), a G7 variant, GX's ordered xie propagation and GX2's vote
+(tools/gen_golden.py g21).  Bars: visit order / flips / signs EXACTLY the reference's, chosen interactions and fields within
+1e-12 (relative to their magnitude), normals exact up to the weight round trip.  Also here: the accuracy of the refined
+v_rsq_f64 / v_rcp_f64 chain against the fp64 C oracle at 1e-13, and the fp64 slab / W / combine entry points through the C ABI.
+GPU only."""
+import socket
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import csr_to_list, load_golden, rel_rowwise
+from dipole_normal_prop_amd import _lib
+from dipole_normal_prop_amd import field_utils as fu
+from dipole_normal_prop_amd import util
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+t = torch.from_numpy
+F64_TOL = 1e-12
+
+
+# ---- the fp64 pair chain itself -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,T", [(3, 5), (257, 300), (1023, 2049), (5000, 700)])
+def test_f64_field_and_potential_against_the_c_oracle_at_1e13(dev, S, T):
+    """Every kernel form a float64 call can take (LDS kernel KT 1 / 4 with padding rows, the direct one-chunk epilogue) on
+    clustered clouds with coincident pairs: rows within 1e-13 of the fp64 C oracle (IEEE sqrt / division there; here
+    v_rsq_f64 / v_rcp_f64 refined by one third-order step, csrc/pair_kernel.h Math<double>)."""
+    gen = torch.Generator().manual_seed(S * 7 + T)
+    src = torch.randn(S, 6, generator=gen, dtype=torch.float64)
+    tgt = torch.randn(T, 6, generator=gen, dtype=torch.float64)
+    src[:, :3] *= 0.3
+    tgt[:, :3] *= 0.3
+    n = min(S, T) // 3
+    tgt[:n, :3] = src[:n, :3]                                          # coincident pairs contribute exactly 0
+    for eps in (1e-5, 1e-6):
+        E = fu.field_grad(src.to(dev), tgt.to(dev), eps=eps).cpu().numpy()
+        ref = c_oracle.field_grad_f64(src.numpy(), tgt.numpy(), eps=eps)
+        assert rel_rowwise(E, ref) < 1e-13
+    far = tgt.clone()
+    far[:, :3] += 5.0                                                   # no coincident pair: the potential is finite
+    phi = fu.potential(src.to(dev), far.to(dev)).cpu().numpy()
+    ref = c_oracle.potential_f64(src.numpy(), far.numpy())
+    assert np.abs(phi - ref).max() <= 1e-13 * np.abs(ref).max()
+    phi0 = fu.potential(src.to(dev), tgt.to(dev)).cpu().numpy()         # a coincident pair: 0/0 -> NaN -> the leaf row is 0
+    assert np.all(phi0[:n] == 0) and np.all(np.isfinite(phi0))
+
+
+def test_f64_scalar_kernel_rows_on_the_sorted_sphere(dev):
+    """>= 5e8 pairs: the scalar-unit kernel (KT = 2) and the leaf recursion, 30 000^2 on the patch-sorted sphere - 512 sampled
+    rows against the C oracle at 5e-13 (measured 1.6e-13: rows of 30 000 terms up to 1e7 each, summed in another order than the
+    oracle's - the contract is 1e-12), and the fp32 kernel beside it (1e-5)."""
+    from tools.workloads import headline_workload
+    pc, patches, _ = headline_workload()
+    idx = torch.cat([p for p in patches])
+    pts = pc[idx][:30000].double()
+    E = fu.field_grad(pts.to(dev), pts.to(dev)).cpu().numpy()
+    rows = np.random.default_rng(5).choice(30000, 512, replace=False)
+    ref = c_oracle.field_grad_f64(pts.numpy(), pts.numpy()[rows])
+    assert rel_rowwise(E[rows], ref) < 5e-13
+    E32 = fu.field_grad(pts.float().to(dev), pts.float().to(dev)).cpu().numpy()
+    assert rel_rowwise(E32[rows], ref) < 1e-5
+
+
+def test_f64_negative_and_zero_eps_keep_the_ieee_chain(dev):
+    """eps <= 0 takes the explicit chain (IEEE root and division in fp64): coincident pairs -> NaN row -> 0 for eps == 0."""
+    gen = torch.Generator().manual_seed(11)
+    src = torch.randn(400, 6, generator=gen, dtype=torch.float64)
+    tgt = torch.randn(300, 6, generator=gen, dtype=torch.float64)
+    tgt[:10, :3] = src[:10, :3]
+    for eps in (0.0, -1e-7):
+        E = fu.field_grad(src.to(dev), tgt.to(dev), eps=eps).cpu().numpy()
+        ref = c_oracle.field_grad_f64(src.numpy(), tgt.numpy(), eps=eps)
+        ok = np.isfinite(ref).all(axis=1) & (np.abs(ref).sum(axis=1) > 0)
+        assert rel_rowwise(E[ok], ref[ok]) < 1e-12
+    fu.flush_warnings()
+
+
+# ---- fp64 slabs, W and the signed combine through the drivers' helpers -----------------------------------------------
+def test_f64_patch_slabs_interactions_and_combine(dev):
+    g = load_golden("G6_patch_propagation")
+    pts = t(g["pc_patchflip"]).double().to(dev)
+    allp = csr_to_list(g["patch_off"], g["patch_idx"])
+    N, P = pts.shape[0], len(allp)
+    off, idx, sizes = util.patch_csr(allp, dev)
+    # gathered patches (the LDS kernel) ...
+    point_patch = fu._point_patch_ids(idx, sizes, N)
+    dE = fu._patch_slabs(pts, off, idx, point_patch, 0, P, 1e-5)
+    assert dE.dtype == torch.float64 and dE.shape == (P, N, 3)
+    cpu = pts.cpu()
+    for k in (0, 17, P - 1):
+        others = torch.ones(N, dtype=torch.bool)
+        others[allp[k]] = False
+        ref = c_oracle.field_grad_f64(cpu[allp[k]].numpy(), cpu[others].numpy())
+        assert rel_rowwise(dE[k].cpu()[others], ref) < 1e-13
+        assert float(dE[k][allp[k].to(dev)].abs().max()) == 0
+    # ... and the patch-sorted layout (the scalar-unit kernel, with the interaction partials out of its epilogue)
+    swork = pts[idx].contiguous()
+    sorted_patch = point_patch[idx].contiguous()
+    tiles = fu._TileTables(swork, sizes)
+    assert tiles.boxes is None                                          # no far-field chain in fp64
+    ranges_off = off
+    dS, W = fu._slabs_and_rows(swork, ranges_off, sorted_patch, 0, P, 1e-5, None, tiles, sizes)
+    assert dS.dtype == torch.float64
+    back = torch.empty_like(dS)
+    back[:, idx] = dS
+    assert float((back - dE).abs().max()) <= 1e-13 * float(dE.abs().max())
+    W3 = fu._interaction_rows(dS, swork, ranges_off, None)
+    dots = (dS * swork[None, :, 3:]).sum(-1).cpu().numpy()
+    ends = np.cumsum(sizes)
+    Wref = np.stack([np.add.reduceat(dots[k], np.concatenate([[0], ends[:-1]])) for k in range(P)])
+    scale = np.abs(Wref).max()
+    assert np.abs(W3.cpu().numpy() - Wref).max() <= 1e-13 * scale
+    if tiles.fused:
+        assert np.abs(W.cpu().numpy() - Wref).max() <= 1e-13 * scale
+    part = fu._patch_slabs(swork, ranges_off, None, sorted_patch, 10, 20, 1e-5)
+    assert torch.equal(part, dS[10:20])
+    sig = (torch.randint(0, 2, (P,), generator=torch.Generator().manual_seed(2)) * 2 - 1).double().to(dev)
+    E64 = torch.empty(N, 3, dtype=torch.float64, device=dev)
+    fu._combine_signed(dS, sig, 0, E64, False)
+    want = (dS * sig[:, None, None]).sum(dim=0)
+    assert float((E64 - want).abs().max()) <= 1e-13 * float(want.abs().max())
+    parts = torch.zeros(N, 3, dtype=torch.float64, device=dev)
+    for lo, hi in ((0, 20), (20, 21), (21, P)):
+        fu._combine_signed(dS[lo:hi], sig, lo, parts, True)
+    assert float((parts - E64).abs().max()) <= 1e-14 * float(E64.abs().max())
+
+
+def test_f64_interaction_partials_out_of_the_epilogue(dev):
+    """Patches of >= 128 points (the first 14 patches of the bench cloud, ~390 points each): every 128-row tile lies inside two
+    groups, so W comes out of the fp64 pair kernel's epilogue (dnp_interactions_from_tiles) - the same numbers as the second pass
+    over the slabs (dnp_interactions_f64) up to fp64 reassociation, and a whole driver call on that cloud equals its literal
+    step-by-step form."""
+    from tools.workloads import headline_workload
+    pc, patches, _ = headline_workload()
+    sel = patches[:14]
+    sizes = np.array([len(p) for p in sel])
+    swork = pc[torch.cat(sel)].double().to(dev)
+    N, P = swork.shape[0], len(sel)
+    off = t(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)).to(dev)
+    sorted_patch = torch.repeat_interleave(torch.arange(P, device=dev), t(sizes).to(dev))
+    tiles = fu._TileTables(swork, sizes)
+    assert tiles.fused
+    dS, W = fu._slabs_and_rows(swork, off, sorted_patch, 0, P, 1e-5, None, tiles, sizes)
+    W3 = fu._interaction_rows(dS, swork, off, None)
+    assert float((W - W3).abs().max()) <= 1e-13 * float(W3.abs().max())
+    ref = c_oracle.field_grad_f64(swork[: sizes[0]].cpu().numpy(), swork[sizes[0]:].cpu().numpy())
+    assert rel_rowwise(dS[0].cpu()[sizes[0]:], ref) < 1e-13
+    ranges = util.PatchList(torch.arange(N, device=dev), sizes, disjoint=True)
+    a, b = swork.clone(), swork.clone()
+    a[torch.arange(N, device=dev) % 3 == 0, 3:] *= -1
+    b.copy_(a)
+    fu.strongest_field_propagation(a, list(enumerate(ranges)), ranges, diffuse=True)
+    tr_a = fu.last_trace("patches")
+    import unittest.mock as um
+    with um.patch.object(fu, "PATCH_MODE", "sequential"):
+        fu.strongest_field_propagation(b, list(enumerate(ranges)), ranges, diffuse=True)
+    tr_b = fu.last_trace("patches")
+    assert np.array_equal(tr_a["order"], tr_b["order"]) and torch.equal(a, b)
+
+
+# ---- the drivers against the reference's float64 runs (G21) ------------------------------------------------------------
+def _check_trace(tr, g, tag, label):
+    assert tr["start"] == int(g[f"order_{tag}"][0])
+    assert np.array_equal(tr["order"], g[f"order_{tag}"])
+    assert np.array_equal((tr["sigma"] < 0)[tr["order"]], g[f"flipped_{tag}"])
+    want = g[f"chosen_{tag}"]
+    dev_ = np.abs(np.asarray(tr["chosen"]) - want) / np.abs(want)
+    # the chosen interaction is a sum over a patch of E . n with E itself a signed sum of slabs: cancellation residues on the
+    # point-scrambled cloud - the bound is relative to the chosen value itself, 1e-10 leaves the reference's own fp64
+    # reassociation (its E is accumulated in visit order) three decades of room and is six decades below the fp32 drivers' 6e-5
+    assert dev_.max() <= 1e-10, (label, float(dev_.max()))
+
+
+@pytest.mark.parametrize("mode", ["batched", "sequential"])
+@pytest.mark.parametrize("tag", ["pf_d_w", "sc_n_nw", "pf_d_nw"])
+def test_G21_float64_patch_propagation(dev, tag, mode, monkeypatch):
+    g6, g = load_golden("G6_patch_propagation"), load_golden("G21_f64_drivers")
+    cname, dflag, wflag = tag.split("_")
+    cloud = t(g6["pc_patchflip"] if cname == "pf" else g6["pc_scrambled"]).double()
+    allp = csr_to_list(g6["patch_off"], g6["patch_idx"])
+    w = t(g6["weights"]).double() if wflag == "w" else None
+    monkeypatch.setattr(fu, "PATCH_MODE", mode)
+    pts = cloud.clone().to(dev)
+    allp_dev = [p.to(dev) for p in allp]
+    filt = [(int(i), allp_dev[int(i)]) for i in g6["filtered"]]
+    fu.strongest_field_propagation(pts, filt, allp_dev, diffuse=(dflag == "d"), weights=None if w is None else w.to(dev))
+    assert pts.dtype == torch.float64
+    _check_trace(fu.last_trace("patches"), g, f"g6_{tag}", f"G21 {tag} {mode}")
+    out = pts.cpu()
+    assert np.array_equal(((out[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g[f"sign_g6_{tag}"])
+    # normals: +-1 times the input (x w / w in fp64 when weighted: an ulp or two)
+    assert np.abs(out[:, 3:].numpy() - g[f"normals_g6_{tag}"]).max() <= (4e-16 if w is not None else 0.0)
+    assert torch.equal(out[:, :3], cloud[:, :3])
+
+
+def test_G21_float64_patch_propagation_is_not_the_fp32_path(dev, monkeypatch):
+    """The float64 call must run the fp64 kernels: its slabs are requested in float64 (a spy on the slab helper), and a
+    host float64 tensor comes back float64, written in place."""
+    g6 = load_golden("G6_patch_propagation")
+    cloud = t(g6["pc_patchflip"]).double()
+    allp = csr_to_list(g6["patch_off"], g6["patch_idx"])
+    seen = []
+    real = fu._patch_slabs
+
+    def spy(work, *a, **k):
+        seen.append(work.dtype)
+        return real(work, *a, **k)
+    monkeypatch.setattr(fu, "_patch_slabs", spy)
+    host = cloud.clone()
+    fu.strongest_field_propagation(host, [(i, p) for i, p in enumerate(allp)], allp, diffuse=True)
+    assert seen and all(d == torch.float64 for d in seen)
+    assert host.dtype == torch.float64 and torch.equal(host[:, :3], cloud[:, :3])
+    g = load_golden("G21_f64_drivers")
+    assert np.array_equal(fu.last_trace("patches")["order"], g["order_g6_pf_d_nw"])
+    seen.clear()
+    f32 = cloud.float().clone()
+    fu.strongest_field_propagation(f32, [(i, p) for i, p in enumerate(allp)], allp, diffuse=True)
+    assert seen and all(d == torch.float32 for d in seen)
+
+
+def test_G21_float64_reps_propagation(dev):
+    g7, g = load_golden("G7_reps_propagation"), load_golden("G21_f64_drivers")
+    cloud = t(g7["pc_patchflip"]).double()
+    reps = list(zip(csr_to_list(g7["rep_off_50"], g7["rep_idx_50"]), csr_to_list(g7["rest_off_50"], g7["rest_idx_50"])))
+    pts = cloud.clone().to(dev)
+    fu.strongest_field_propagation_reps(pts, [(a.to(dev), b.to(dev)) for a, b in reps], diffuse=True)
+    assert pts.dtype == torch.float64
+    _check_trace(fu.last_trace("reps"), g, "g7_50_d", "G21 reps 50_d")
+    out = pts.cpu()
+    assert np.array_equal(((out[:, 3:] * cloud[:, 3:]).sum(-1) > 0).numpy(), g["sign_g7_50_d"])
+    assert np.array_equal(out[:, 3:].numpy(), g["normals_g7_50_d"])
+    # the RepLists form the callers pass (partition known: the fused tail on the sub-cloud)
+    i64 = lambda a: t(a.astype(np.int64)).to(dev)
+    rl = util.RepLists(util.PatchList(i64(g7["rep_idx_50"]), np.diff(g7["rep_off_50"]), disjoint=True),
+                       util.PatchList(i64(g7["rest_idx_50"]), np.diff(g7["rest_off_50"]), disjoint=True))
+    pts2 = cloud.clone().to(dev)
+    fu.strongest_field_propagation_reps(pts2, rl, diffuse=True)
+    assert torch.equal(pts2, pts)
+
+
+# ---- xie: float64 matrix, ordered propagation, BFS-route vote ------------------------------------------------------------
+def test_G21_float64_xie_matrix_and_ordered_propagation(dev):
+    gx, g = load_golden("GX_xie"), load_golden("G21_f64_drivers")
+    pc = t(gx["pc"]).double().to(dev)
+    M = fu.xie_intersaction(pc, pc, eps=0.1, knn_mask=-1, C=3)
+    assert M.dtype == torch.float64
+    ref = g["xie_inter_pc64"]
+    assert np.abs(M[:64].cpu().numpy() - ref).max() <= F64_TOL * np.abs(ref).max()
+    for diffuse, key in ((False, "xie_flip_n"), (True, "xie_flip_d")):
+        res = fu.xie_propagation_points_in_order(pc, 0.1, gx["orders"], diffuse=diffuse, knn_mask=-1, C=3)
+        assert res.dtype == torch.bool and np.array_equal(res.cpu().numpy(), g[key])
+    assert pc.dtype == torch.float64
+
+
+def test_G21_float64_bfstree_vote(dev):
+    gx2, g = load_golden("GX2_xie_bfstree"), load_golden("G21_f64_drivers")
+    pts = t(gx2["pc"]).double().clone().to(dev)
+    res = fu.xie_propagation_points_onbfstree(pts, 0.1, diffuse=True, starting_point=0, k=10, treshold=0.1, times=5,
+                                              knn_mask=-1, C=3)
+    tr = fu.last_trace("bfstree")
+    assert np.array_equal(tr["orders"], g["bfs_orders_t5_d"])
+    assert np.array_equal(tr["flips"], g["bfs_flips_t5_d"])
+    assert np.array_equal(tr["status"], g["bfs_status_t5_d"])
+    assert np.array_equal(res.cpu().numpy(), g["bfs_result_t5_d"])
+    assert pts.dtype == torch.float64 and np.array_equal(pts.cpu().numpy()[:, 3:], g["bfs_normals_t5_d"])
+
+
+def _order_spec(M, order, dtype):
+    """The ordered propagation as specified (csrc/dnp_xie.hip): products rounded in the matrix's precision, fp64 sums - thread
+    t of 1024 adds its columns t, t + 1024, ... in ascending order, each wavefront folds its 64 sums by halving, the 16
+    wavefront sums are added in order - and the sign of the total rounded to `dtype` becomes the weight.  Entries of points
+    the order never visits stay 0."""
+    N = M.shape[0]
+    pad = -(-N // 1024) * 1024
+    w = np.zeros(N, dtype=dtype)
+    inter = np.zeros(N, dtype=dtype)
+    for idx in order:
+        p = np.zeros(pad, dtype=np.float64)
+        p[:N] = (M[idx] * w).astype(dtype)
+        s = np.zeros(1024)
+        for k in range(pad // 1024):
+            s = s + p[k * 1024:(k + 1) * 1024]
+        v = s.reshape(16, 64).copy()
+        for off in (32, 16, 8, 4, 2, 1):
+            v[:, :off] = v[:, :off] + v[:, off:2 * off]
+        tot = 0.0
+        for k in range(16):
+            tot = tot + v[k, 0]
+        inter[idx] = dtype(tot)
+        w[idx] = -1.0 if inter[idx] < 0 else 1.0
+    return inter, w
+
+
+@pytest.mark.parametrize("n,dtype", [(900, torch.float32), (6000, torch.float32), (16500, torch.float32),
+                                     (900, torch.float64), (6000, torch.float64), (12500, torch.float64)])
+def test_xie_order_row_with_a_repeated_and_a_missing_index(dev, n, dtype):
+    """An `order` row that is not a permutation - one index repeated, another one missing (round-3 advisor, round-4 verdict) - in
+    EVERY kernel form: the register forms (fp32: N <= 4096 / <= 16 384; fp64: <= 4096 / <= 12 288) and the plain form with the
+    weights in memory (beyond).  The buffers are poisoned first: the product hands the kernels torch.empty memory.  The
+    unvisited point must come back with interaction 0 (flip False, as the reference's torch.zeros) and weight 0, every other
+    entry is the specification's bit for bit - which also makes register form == plain form."""
+    lib = _lib.require_device()
+    gen = torch.Generator().manual_seed(n)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    M = (torch.rand(n, n, generator=gen, dtype=torch.float64) - 0.5).to(dtype)
+    order = np.random.default_rng(n).permutation(n).astype(np.int64)
+    missing, repeated = int(order[n // 2]), int(order[n // 3])
+    order[n // 2] = repeated                                            # `repeated` is visited twice, `missing` never
+    order_t = t(np.stack([order, np.random.default_rng(1).permutation(n)])).to(dev)
+    weights = torch.full((2, n), 7.0, dtype=dtype, device=dev)
+    inter = torch.full((2, n), -7.0, dtype=dtype, device=dev)
+    Md = M.to(dev)
+    fn = lib.dnp_xie_order_f32 if dtype == torch.float32 else lib.dnp_xie_order_f64
+    assert fn(_lib.ptr(Md), n, _lib.ptr(order_t), 2, _lib.ptr(weights), _lib.ptr(inter), _lib.current_stream()) == 0
+    inter_h, w_h = inter.cpu().numpy(), weights.cpu().numpy()
+    assert inter_h[0, missing] == 0 and w_h[0, missing] == 0           # never visited: 0, not the poison
+    want_i, want_w = _order_spec(M.numpy(), order, npdt)
+    assert np.array_equal(inter_h[0], want_i) and np.array_equal(w_h[0], want_w)
+    # the diffuse pass behind it (dnp_xie_rowdots_*): one wavefront per row, lane-strided fp64 sums, butterfly
+    out = torch.full((2, n), 3.0, dtype=dtype, device=dev)
+    rd = lib.dnp_xie_rowdots_f32 if dtype == torch.float32 else lib.dnp_xie_rowdots_f64
+    assert rd(_lib.ptr(Md), n, _lib.ptr(weights), 2, _lib.ptr(out), _lib.current_stream()) == 0
+    ref = (M.double() @ weights.cpu().double().T).T.numpy()
+    scale = (M.double().abs() @ weights.cpu().double().abs().T).T.numpy()
+    tol = 1e-6 if dtype == torch.float32 else 1e-14
+    assert np.all(np.abs(out.cpu().numpy() - ref) <= tol * scale)
+
+
+def test_xie_product_path_with_a_non_permutation_order(dev):
+    """The same through field_utils.xie_propagation_points_in_order (which allocates the kernel's buffers with torch.empty):
+    an unvisited point reads False in the ordered form; fp32 and fp64 agree on this cloud."""
+    gx = load_golden("GX_xie")
+    pc = t(gx["pc"]).to(dev)
+    n = pc.shape[0]
+    order = np.arange(n)
+    order[10] = 3                                                       # 3 twice, 10 never
+    torch.empty((4, n), dtype=torch.float32, device=dev).fill_(-1.0)    # leave poison where the next torch.empty lands
+    r32 = fu.xie_propagation_points_in_order(pc, 0.1, [order], diffuse=False)
+    r64 = fu.xie_propagation_points_in_order(pc.double(), 0.1, [order], diffuse=False)
+    assert not bool(r32[0, 10]) and not bool(r64[0, 10])
+    assert torch.equal(r32, r64)
+
+
+# ---- sharded: two ranks on one card (gloo collectives), float64 ----------------------------------------------------------
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dipole_normal_prop_amd import parallel
+        g6 = load_golden("G6_patch_propagation")
+        dev = torch.device("cuda:0")
+        cloud = torch.from_numpy(g6["pc_patchflip"]).double()
+        allp = csr_to_list(g6["patch_off"], g6["patch_idx"])
+        allp_dev = [p.to(dev) for p in allp]
+        filt = [(int(i), allp_dev[int(i)]) for i in g6["filtered"]]
+        w = torch.from_numpy(g6["weights"]).double().to(dev)
+        pts = cloud.clone().to(dev)
+        parallel.sharded_patch_propagation(pts, filt, allp_dev, diffuse=True, weights=w)
+        tr = fu.last_trace("sharded")
+        q.put((rank, tr["start"], tr["order"].copy(), (tr["sigma"] < 0)[tr["order"]].copy(), np.asarray(tr["chosen"]).copy(),
+               pts.cpu().numpy().copy(), str(pts.dtype)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_G21_float64_sharded_over_two_ranks(dev):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda x: x[0])
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    g = load_golden("G21_f64_drivers")
+    for rank, start, order, flipped, chosen, out, dtype in res:
+        assert dtype == "torch.float64"
+        assert start == int(g["order_g6_pf_d_w"][0]) and np.array_equal(order, g["order_g6_pf_d_w"])
+        assert np.array_equal(flipped, g["flipped_g6_pf_d_w"])
+        assert np.abs(chosen - g["chosen_g6_pf_d_w"]).max() <= 1e-10 * np.abs(g["chosen_g6_pf_d_w"]).max()
+        assert np.abs(out[:, 3:] - g["normals_g6_pf_d_w"]).max() <= 4e-16
+    assert np.array_equal(res[0][5], res[1][5])

@@ -356,8 +356,8 @@ def test_tile_tables_and_fused_interaction_rows(dev):
     dnp_tile_boxes_f32 equals per-tile min / max; the slabs are bit-identical with and without the tile table and with
     and without the partials; W assembled from the partials (dnp_interactions_from_tiles) equals the K3 pass over the
     slabs up to fp64 reassociation - on boxunion (369 patches of >= 100 points: some 128-row tiles straddle three
-    patches, so the driver must refuse the fused form there) and on a cut with patches of >= 128 points plus rows
-    that are in no patch (fused form allowed)."""
+    patches; rounds 3-4 refused the fused form there, round 5 gives the partials a third group slot) and on a cut with
+    patches of >= 128 points plus rows that are in no patch (two slots)."""
     lib = _lib.require_device()
     g = load_golden("G15_boxunion_config3")
     cloud = t(g["pc"]).to(dev)
@@ -369,7 +369,7 @@ def test_tile_tables_and_fused_interaction_rows(dev):
     tiles = fu._TileTables(swork, np.diff(off_np))
     ref = torch.stack([torch.cat([swork[i:i + R, :3].min(0).values, swork[i:i + R, :3].max(0).values]) for i in range(0, N, R)])
     assert tiles.n_tiles == ref.shape[0] and torch.equal(tiles.boxes, ref)
-    assert not tiles.fused                               # min patch 100 < 128 rows: a tile can hold three patches
+    assert tiles.fused and tiles.slots == 3              # min patch 100 < 128 rows: a tile can hold three patches
     off = t(off_np).to(dev)
     P = len(off_np) - 1
     point_patch = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
@@ -377,8 +377,15 @@ def test_tile_tables_and_fused_interaction_rows(dev):
     boxed = fu._patch_slabs(swork, off, None, point_patch, 100, 140, 1e-5, boxes)
     tiled = fu._patch_slabs(swork, off, None, point_patch, 100, 140, 1e-5, boxes, tiles.boxes)
     assert torch.equal(boxed, tiled)
-    dE, W = fu._slabs_and_rows(swork, off, point_patch, 100, 140, 1e-5, boxes, tiles)     # falls back to K3
-    assert torch.equal(dE, boxed) and torch.equal(W, fu._interaction_rows(boxed, swork, off, None))
+    dE, W = fu._slabs_and_rows(swork, off, point_patch, 100, 140, 1e-5, boxes, tiles)     # three-slot partials
+    W3 = fu._interaction_rows(boxed, swork, off, None)
+    assert torch.equal(dE, boxed) and float((W - W3).abs().max()) <= 1e-12 * float(W3.abs().max())
+    dE, W = fu._slabs_and_rows(swork, off, point_patch, 0, P, 1e-5, boxes, tiles, np.diff(off_np))   # all 369, split tail rule
+    W3 = fu._interaction_rows(dE, swork, off, None)
+    assert float((W - W3).abs().max()) <= 1e-12 * float(W3.abs().max())
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert lib.dnp_check_tile_groups(_lib.ptr(point_patch), N, 3, _lib.ptr(bad), _lib.current_stream()) == 0 and int(bad.item()) == 0
+    assert lib.dnp_check_tile_groups(_lib.ptr(point_patch), N, 2, _lib.ptr(bad), _lib.current_stream()) == 0 and int(bad.item()) > 0
 
     # a cut that allows the fused form: patches of 128..700 rows over the first 90 000 rows, the rest in no patch
     rng = np.random.default_rng(3)
@@ -396,7 +403,7 @@ def test_tile_tables_and_fused_interaction_rows(dev):
     pp2 = torch.cat([torch.repeat_interleave(torch.arange(P2, device=dev), off2[1:] - off2[:-1]),
                      torch.full((N - covered,), -1, dtype=torch.int64, device=dev)])
     tiles2 = fu._TileTables(swork, sizes)
-    assert not tiles2.fused                               # the empty patch makes a tile's group ids jump by two: refused
+    assert not tiles2.fused                               # an empty patch makes a tile's group ids jump: refused
     sizes3 = np.array(sizes[:-2].tolist() + [300], dtype=np.int64)
     off3_np = np.concatenate([[0], np.cumsum(sizes3)])
     off3 = t(off3_np).to(dev)
@@ -404,7 +411,7 @@ def test_tile_tables_and_fused_interaction_rows(dev):
     pp3 = torch.cat([torch.repeat_interleave(torch.arange(P3, device=dev), off3[1:] - off3[:-1]),
                      torch.full((N - int(off3_np[-1]),), -1, dtype=torch.int64, device=dev)])
     tiles3 = fu._TileTables(swork, sizes3)
-    assert tiles3.fused
+    assert tiles3.fused and tiles3.slots == 2
     boxes3 = fu._patch_boxes(swork, off3, None)
     for b0, b1 in ((0, P3), (7, 31)):
         dE, W = fu._slabs_and_rows(swork, off3, pp3, b0, b1, 1e-5, boxes3, tiles3)
@@ -430,16 +437,20 @@ def test_tile_group_precondition_is_checkable_on_the_device(dev):
     g = torch.Generator().manual_seed(11)
     x = torch.randn(1000, 3, generator=g)
     pc = torch.cat([0.4 * x / x.norm(dim=1, keepdim=True), x / x.norm(dim=1, keepdim=True)], 1).to(dev)
-    for sizes, want_ok in ((np.array([300, 200, 380, 120]), True), (np.array([300, 100, 20, 300, 280]), False)):
+    for sizes, want_ok, slots in ((np.array([300, 200, 380, 120]), True, 2), (np.array([300, 100, 20, 300, 280]), False, 3),
+                                  (np.array([300, 60, 20, 30, 310, 280]), False, 0)):
         off = t(np.concatenate([[0], np.cumsum(sizes)])).to(dev)
         pp = torch.repeat_interleave(torch.arange(len(sizes), device=dev), off[1:] - off[:-1])
         bad = torch.zeros(1, dtype=torch.int32, device=dev)
-        assert lib.dnp_check_tile_groups(_lib.ptr(pp), 1000, _lib.ptr(bad), _lib.current_stream()) == 0
+        assert lib.dnp_check_tile_groups(_lib.ptr(pp), 1000, 2, _lib.ptr(bad), _lib.current_stream()) == 0
         assert (int(bad.item()) == 0) == want_ok
+        bad3 = torch.zeros(1, dtype=torch.int32, device=dev)
+        assert lib.dnp_check_tile_groups(_lib.ptr(pp), 1000, 3, _lib.ptr(bad3), _lib.current_stream()) == 0
+        assert (int(bad3.item()) == 0) == (slots != 0)
         assert fu._tiles_within_two_groups(sizes, 1000, 128) == want_ok
         boxes, tiles = fu._patch_boxes(pc, off, None), fu._TileTables(pc, sizes)
-        assert tiles.fused == want_ok
-        if want_ok:
+        assert tiles.slots == slots and tiles.fused == (slots != 0)
+        if slots:
             dE, W = fu._slabs_and_rows(pc, off, pp, 0, len(sizes), 1e-5, boxes, tiles, sizes)
             W3 = fu._interaction_rows(dE, pc, off, None)
             assert float((W - W3).abs().max()) <= 1e-12 * float(W3.abs().max())
@@ -488,13 +499,13 @@ def test_source_split_does_not_change_a_bit(dev):
     for k in (5, 2):
         dEr = torch.full((24, N, 3), float("nan"), dtype=torch.float32, device=dev)
         rc = lib.dnp_patch_fields_tiled_f32(_lib.ptr(swork), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch), _lib.ptr(boxes),
-                                            _lib.ptr(tiles.boxes), 40, 64, 1e-5, _lib.ptr(dEr), None, -k, _lib.ptr(own), nb,
+                                            _lib.ptr(tiles.boxes), 40, 64, 1e-5, _lib.ptr(dEr), None, 2, -k, _lib.ptr(own), nb,
                                             _lib.current_stream())
         assert rc == 0 and torch.equal(dEr, res[1][0]), k
     # a split launch without the buffer is refused, not run wrong
     dE = torch.empty((24, N, 3), dtype=torch.float32, device=dev)
     rc = _lib.load().dnp_patch_fields_tiled_f32(_lib.ptr(swork), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch), _lib.ptr(boxes),
-                                                _lib.ptr(tiles.boxes), 40, 64, 1e-5, _lib.ptr(dE), None, -3, None, 0,
+                                                _lib.ptr(tiles.boxes), 40, 64, 1e-5, _lib.ptr(dE), None, 2, -3, None, 0,
                                                 _lib.current_stream())
     assert rc == -3 and b"exchange buffer" in _lib.load().dnp_last_error()
     k = 51

@@ -24,14 +24,16 @@ def test_tabled_pair_kernels_keep_their_register_and_lds_budget():
         if m:
             rows[m.group(1).strip()] = tuple(int(x) for x in m.groups()[1:])
     tabled = {k: v for k, v in rows.items() if k.startswith("pair_kernel_scalar<float, float, 0, 2, 0, true, true, true")}
-    assert len(tabled) == 4, sorted(rows)                      # plain / exchange-tail form, each with and without the partials
+    assert len(tabled) == 6, sorted(rows)                      # plain / exchange-tail form, each without the partials and with 2 / 3 group slots
     for name, (vgpr, sgpr, lds, occ, scratch) in tabled.items():
         assert vgpr <= 64 and occ == 8, (name, vgpr, occ)      # 8 wavefronts per SIMD
         assert sgpr <= 80, (name, sgpr)                        # above 80 the hardware admits 7 (MI355X_MICROARCH.md)
         assert lds == 0 and scratch == 0, (name, lds, scratch)
     for name, (vgpr, sgpr, lds, occ, scratch) in rows.items():
-        if name.startswith("pair_kernel_scalar"):
+        if name.startswith("pair_kernel_scalar<float"):
             assert vgpr <= 64 and scratch == 0, (name, vgpr, scratch)
+        if name.startswith("pair_kernel_scalar<double"):           # round 5, fp64 slabs: KT = 2 in doubles, >= 4 wavefronts per SIMD
+            assert vgpr <= 128 and occ >= 4 and scratch == 0 and lds == 0, (name, vgpr, occ, scratch, lds)
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not found")

@@ -867,6 +867,102 @@ def g20(fu, util):
     save("G20_fandisk_caller_pipelines", **out)
 
 
+def g21(fu, util):
+    """Round 5: the drivers on FLOAT64 clouds (the reference computes in the dtype it is handed, field_utils.py:96-109, :286-348,
+    :207-282, :569-605; its socket path hands it float64, util.py:71-77).  The clouds, patches, representatives and routes are
+    those of G6 / G7 / GX / GX2 cast to float64 - only the reference's float64 OUTPUTS are stored here: order / flipped / chosen /
+    signs / normals of two G6 variants and one G7 variant, the ordered xie propagation (GX's three orders, plain and diffuse) and
+    the BFS-route vote t5_d."""
+    import itertools
+    g6 = np.load(os.path.join(OUT, "G6_patch_propagation.npz"))
+    off = g6["patch_off"]
+    idx = torch.from_numpy(g6["patch_idx"])
+    allp = [idx[off[k]:off[k + 1]] for k in range(len(off) - 1)]
+    filtered = g6["filtered"]
+    patches = [(int(i), allp[int(i)]) for i in filtered]
+    out = {}
+    for cname, key, diffuse, use_w in (("pf", "pc_patchflip", True, True), ("sc", "pc_scrambled", False, False),
+                                       ("pf", "pc_patchflip", True, False)):
+        cloud = torch.from_numpy(g6[key]).double()
+        w = torch.from_numpy(g6["weights"]).double() if use_w else None
+        tag = f"g6_{cname}_{'d' if diffuse else 'n'}_{'w' if use_w else 'nw'}"
+        t0 = time.time()
+        pts, calls, inter = _run_patch_driver(fu, util, "patch", cloud, patches, allp, diffuse, w)
+        assert pts.dtype == torch.float64 and inter[0].dtype == torch.float64
+        base = cloud if w is None else torch.cat([cloud[:, :3], cloud[:, 3:] * w.clamp(0.1, 1)[:, None]], 1)
+        firsts = [(int(p[0]), base[int(p[0]), :3]) for p in allp]
+        mins = [(int(p.min()), base[int(p.min()), :3]) for p in allp]
+        order, flipped = _order_from_calls(calls, base, firsts, mins)
+        out[f"order_{tag}"] = order
+        out[f"flipped_{tag}"] = flipped
+        out[f"chosen_{tag}"] = np.array([float(t[t.abs().argmax()]) for t in inter])
+        out[f"sign_{tag}"] = ((pts[:, 3:] * cloud[:, 3:]).sum(-1) > 0)
+        out[f"normals_{tag}"] = pts[:, 3:]
+        print(f"  G21 {tag}: {time.time() - t0:.1f}s, start patch {order[0]}")
+    # G7, cap 50, diffuse (rests are non-empty), float64
+    g7 = np.load(os.path.join(OUT, "G7_reps_propagation.npz"))
+    cloud = torch.from_numpy(g7["pc_patchflip"]).double()
+    ro, ri = g7["rep_off_50"], torch.from_numpy(g7["rep_idx_50"])
+    so, si = g7["rest_off_50"], torch.from_numpy(g7["rest_idx_50"])
+    reps = [(ri[ro[k]:ro[k + 1]], si[so[k]:so[k + 1]]) for k in range(len(ro) - 1)]
+    t0 = time.time()
+    pts, calls, inter = _run_patch_driver(fu, util, "reps", cloud, reps, None, True, None)
+    assert pts.dtype == torch.float64
+    firsts = [(int(r[0]), cloud[int(r[0]), :3]) for r, _ in reps]
+    mins = [(int(r.min()), cloud[int(r.min()), :3]) for r, _ in reps]
+    order, flipped = _order_from_calls(calls[:len(reps)], cloud, firsts, mins)
+    out["order_g7_50_d"] = order
+    out["flipped_g7_50_d"] = flipped
+    out["chosen_g7_50_d"] = np.array([float(t[t.abs().argmax()]) for t in inter])
+    out["sign_g7_50_d"] = ((pts[:, 3:] * cloud[:, 3:]).sum(-1) > 0)
+    out["normals_g7_50_d"] = pts[:, 3:]
+    print(f"  G21 g7_50_d: {time.time() - t0:.1f}s, start patch {order[0]}")
+    # the ordered xie propagation in float64 (GX's cloud and orders), plain and diffuse; a float64 slice of the matrix
+    gxf = np.load(os.path.join(OUT, "GX_xie.npz"))
+    pc = torch.from_numpy(gxf["pc"]).double()
+    for diffuse in (False, True):
+        res = fu.xie_propagation_points_in_order(pc.clone(), 0.1, gxf["orders"], diffuse=diffuse, knn_mask=-1, C=3)
+        out[f"xie_flip_{'d' if diffuse else 'n'}"] = res
+        print(f"  G21 xie in_order f64 diffuse={diffuse}: flipped {int(res.sum())}")
+    out["xie_inter_pc64"] = fu.xie_intersaction(pc, pc, eps=0.1, knn_mask=-1, C=3)[:64]
+    # the BFS-route vote t5_d in float64 (harness as in gx2)
+    seen = {}
+    orig_in_order, orig_miqp = fu.xie_propagation_points_in_order, fu.MIQP
+
+    def rec_in_order(pts, eps, order, *a, **k):
+        seen["orders"] = np.array(order)
+        res = orig_in_order(pts, eps, order, *a, **k)
+        seen["flips"] = res.clone()
+        return res
+
+    def exhaustive(A, B):
+        n = len(A)
+        best, best_cost = None, None
+        for tail in itertools.product((0, 1), repeat=n - 1):
+            x = np.array((0,) + tail[::-1])
+            cost = fu.cal_loss(x, A, B)
+            if best_cost is None or cost < best_cost:
+                best, best_cost = x, cost
+        seen["status"] = best.astype(bool)
+        return best.astype(float)
+
+    fu.xie_propagation_points_in_order, fu.MIQP = rec_in_order, exhaustive
+    try:
+        pts = pc.clone()
+        res = fu.xie_propagation_points_onbfstree(pts, 0.1, diffuse=True, starting_point=0, k=10, treshold=0.1, times=5,
+                                                  knn_mask=-1, C=3)
+        out["bfs_orders_t5_d"] = seen["orders"]
+        out["bfs_flips_t5_d"] = seen["flips"]
+        out["bfs_status_t5_d"] = seen["status"]
+        out["bfs_result_t5_d"] = res
+        out["bfs_normals_t5_d"] = pts[:, 3:]
+        assert pts.dtype == torch.float64
+        print(f"  G21 bfs t5_d f64: flipped {int(res.sum())}, status {seen['status'].astype(int)}")
+    finally:
+        fu.xie_propagation_points_in_order, fu.MIQP = orig_in_order, orig_miqp
+    save("G21_f64_drivers", **out)
+
+
 def make_inference_shim():
     """inference_utils.py imports models/ (torch_geometric, absent offline) at module level.
     Only its pure-torch fix_n_filter is on the path; load that one function's source object by
@@ -882,7 +978,7 @@ def make_inference_shim():
     spec.loader.exec_module(mod)
 
 
-ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13, G14=g14, G15=g15, G16=g16, GW=gw, GX2=gx2, G17=g17, G18=g18, G19=g19, G20=g20)
+ALL = dict(G1=g1, G2=g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10, G11=g11, G12=g12, GH=gh, GX=gx, G13=g13, G14=g14, G15=g15, G16=g16, GW=gw, GX2=gx2, G17=g17, G18=g18, G19=g19, G20=g20, G21=g21)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -87,7 +87,7 @@ def main():
             rc = libs[name].dnp_patch_fields_tiled_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch),
                                                        _lib.ptr(boxes), _lib.ptr(tile_boxes), 0, P, 1e-5,
                                                        _lib.ptr(dE[name]), _lib.ptr(w_part) if name != "tiled" else None,
-                                                       1, None, 0, stream)
+                                                       2, 1, None, 0, stream)
         else:
             rc = libs[name].dnp_patch_fields_boxed_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch),
                                                        _lib.ptr(boxes), 0, P, 1e-5, _lib.ptr(dE[name]), stream)
@@ -117,11 +117,11 @@ def main():
     W3 = torch.empty((P, P), dtype=torch.float64, device=dev)
     Wt = torch.empty((P, P), dtype=torch.float64, device=dev)
     assert libs["far"].dnp_interactions_f32(_lib.ptr(dE["far"]), P, N, _lib.ptr(pts), 6, _lib.ptr(off), None, P, _lib.ptr(W3), stream) == 0
-    assert libs["far"].dnp_interactions_from_tiles(_lib.ptr(w_part), P, N, _lib.ptr(point_patch), _lib.ptr(off), P, _lib.ptr(Wt), stream) == 0
+    assert libs["far"].dnp_interactions_from_tiles(_lib.ptr(w_part), 2, P, N, _lib.ptr(point_patch), _lib.ptr(off), P, _lib.ptr(Wt), stream) == 0
     torch.cuda.synchronize()
     print(f"W from tiles vs K3: max |diff| / max |W| = {float((Wt - W3).abs().max() / W3.abs().max()):.2e}")
     for label, fn in (("K3 dnp_interactions_f32", lambda: libs["far"].dnp_interactions_f32(_lib.ptr(dE["far"]), P, N, _lib.ptr(pts), 6, _lib.ptr(off), None, P, _lib.ptr(W3), stream)),
-                      ("dnp_interactions_from_tiles", lambda: libs["far"].dnp_interactions_from_tiles(_lib.ptr(w_part), P, N, _lib.ptr(point_patch), _lib.ptr(off), P, _lib.ptr(Wt), stream))):
+                      ("dnp_interactions_from_tiles", lambda: libs["far"].dnp_interactions_from_tiles(_lib.ptr(w_part), 2, P, N, _lib.ptr(point_patch), _lib.ptr(off), P, _lib.ptr(Wt), stream))):
         ts = []
         for _ in range(20):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -100,7 +100,8 @@ def run(budget=180.0, seed=0):
                 base = fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes)
                 tail = -int(rng.integers(1, n_p + 2))             # one launch, its last k patches split (k > n_p: all of them)
                 allp = -(n_p + 1)                                 # every patch of the launch split
-                wp = {ss: torch.full((n_p, tiles.n_tiles, 2), float("nan"), dtype=torch.float64, device=dev) for ss in (1, allp, tail)}
+                slots = tiles.slots if tiles.slots else 2        # (partials are written for ANY cut and only used where the tiles allow)
+                wp = {ss: torch.full((n_p, tiles.n_tiles, slots), float("nan"), dtype=torch.float64, device=dev) for ss in (1, allp, tail)}
                 variants = {"tile table": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes),
                             "partials": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, wp[1], 1),
                             "all split": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, None, allp),
@@ -117,7 +118,7 @@ def run(budget=180.0, seed=0):
                     W3 = fu._interaction_rows(base, sw, off, None)
                     Wt = torch.empty_like(W3)
                     lib = _lib.require_device()
-                    _lib.check(lib.dnp_interactions_from_tiles(_lib.ptr(wp[1]), n_p, N, _lib.ptr(pp), _lib.ptr(off), n_p,
+                    _lib.check(lib.dnp_interactions_from_tiles(_lib.ptr(wp[1]), slots, n_p, N, _lib.ptr(pp), _lib.ptr(off), n_p,
                                                                _lib.ptr(Wt), _lib.current_stream()))
                     scale = float(W3.abs().max())
                     if scale > 0 and float((Wt - W3).abs().max()) > 1e-11 * scale:

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""BASELINE config 3 (boxunion, the reference's 369 patches / representatives) x 4 calls - run under
-rocprofv3 --kernel-trace to see the timeline of the representatives driver."""
+"""BASELINE config 3 (boxunion, the reference's 369 patches / representatives): 4 synchronised calls (lazy initialisation, clock
+ramp), then 12 calls back to back as bench.py's leg makes them - run under rocprofv3 --kernel-trace (tools/profile_config3.sh);
+tools/summarize_trace.py turns the trace into the per-call kernel breakdown (profiles/r05_config3_kernels.txt)."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,3 +18,6 @@ reps = util.RepLists(util.PatchList(i64(g["rep_idx"]), np.diff(g["rep_off"]), di
 for _ in range(4):
     fu.strongest_field_propagation_reps(cloud.clone(), reps, diffuse=True)
     torch.cuda.synchronize()
+for _ in range(12):
+    fu.strongest_field_propagation_reps(cloud.clone(), reps, diffuse=True)
+torch.cuda.synchronize()
