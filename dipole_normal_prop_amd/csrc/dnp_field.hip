@@ -33,7 +33,13 @@ static inline int64_t min_chunk(int64_t S, bool scalar_kernel) {
     return m < 64 ? 64 : (m > DNP_MINCHUNK_CAP ? DNP_MINCHUNK_CAP : m);
 }
 constexpr int kKTScalar = 2, kKTLds = 4;
-constexpr int64_t kTilesForLarge = 16;     // ... used once that still leaves >= 16 target tiles (T >= 8192 / 16384)
+#ifndef DNP_KT_TILES      // A/B builds (tools/gpu_k1_ab.py K1_SHAPES)
+#define DNP_KT_TILES 8
+#endif
+// ... used once that still leaves >= 8 target tiles (T >= 4096 / 8192).  Round 5: 16 -> 8 - the representatives driver's final
+// field (93 411 sources x 6589 targets) 393 -> 375 us, 100 000 x 4096 and 30 000 x 7000 level; 4 costs the latter 20 %
+// (profiles/r05_kt_tiles_ab.txt)
+constexpr int64_t kTilesForLarge = DNP_KT_TILES;
 constexpr size_t kSlabCap = (size_t)1 << 30;  // bytes of partial slab per round
 struct Plan {
     // one entry per round; every round is a run of whole leaves

@@ -551,9 +551,13 @@ int dnp_patch_greedy(const double* W, int64_t P, const int64_t* start, int64_t* 
             hipLaunchKernelGGL((patch_greedy_block_kernel<8>), dim3(1), dim3(kGreedyBlock), 0, st, W, (int)P, start, order, sigma, chosen);
         else
             hipLaunchKernelGGL((patch_greedy_block_kernel<16>), dim3(1), dim3(kGreedyBlock), 0, st, W, (int)P, start, order, sigma, chosen);
-    } else if (P <= 64 * 4) DNP_LAUNCH_PG(4);
+    } else if (P <= 64 * 2) DNP_LAUNCH_PG(2);      // (round 5: 2, 6, 12, 24 - a step's argmax scans EPL entries per lane and the
+    else if (P <= 64 * 4) DNP_LAUNCH_PG(4);          // winner's value is picked out of EPL registers: P = 369 ran as EPL = 8)
+    else if (P <= 64 * 6) DNP_LAUNCH_PG(6);
     else if (P <= 64 * 8) DNP_LAUNCH_PG(8);
+    else if (P <= 64 * 12) DNP_LAUNCH_PG(12);
     else if (P <= 64 * 16) DNP_LAUNCH_PG(16);
+    else if (P <= 64 * 24) DNP_LAUNCH_PG(24);
     else if (P <= 64 * 32) DNP_LAUNCH_PG(32);
     else DNP_LAUNCH_PG(64);
 #undef DNP_LAUNCH_PG

@@ -791,10 +791,16 @@ def test_G6_cpu_tensor_input_default_start(dev, tag):
     fu.strongest_field_propagation(ref, [(i, allp_d[i]) for i, _ in patches], allp_d, diffuse=diffuse,
                                    weights=None if w is None else w.to(dev))
     assert torch.equal(pts, ref.cpu())
+    # a float64 strided host view: propagated in float64 since round 5 (the reference computes in the tensor's dtype) - the same
+    # trace and signs, normals +-1 times the input up to the weight round trip n w / w in fp64, the padding columns untouched
     wide = torch.zeros(cloud.shape[0], 8, dtype=torch.float64)
     wide[:, 1:7] = cloud.double()
     fu.strongest_field_propagation(wide[:, 1:7], patches, allp, diffuse=diffuse, weights=w)
-    assert torch.equal(wide[:, 1:7], ref.cpu().double()) and float(wide[:, 0].abs().max()) == 0 and float(wide[:, 7].abs().max()) == 0
+    assert np.array_equal(fu.last_trace("patches")["order"], g[f"order_{tag}"])
+    assert torch.equal(wide[:, 1:4], cloud[:, :3].double())
+    assert torch.equal((wide[:, 4:7] * cloud[:, 3:].double()).sum(-1) > 0, (ref.cpu()[:, 3:] * cloud[:, 3:]).sum(-1) > 0)
+    assert float((wide[:, 4:7].abs() - cloud[:, 3:].double().abs()).abs().max()) <= (0.0 if w is None else 4e-16)
+    assert float(wide[:, 0].abs().max()) == 0 and float(wide[:, 7].abs().max()) == 0
 
 
 def test_start_patch_rule_matches_the_reference_curvatures(dev):

@@ -41,6 +41,29 @@ def main():
     hpc, hpatches, _ = headline_workload()
     clouds["sorted100k"] = hpc.to(dev)[util.patch_csr(hpatches, dev)[1]].contiguous()   # the bench cloud, sorted by patch
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # rectangular shapes "S x T,S x T": the first S rows of the UNSORTED 100k sphere as sources, T gathered target rows
+    for shape in [v for v in os.environ.get("K1_SHAPES", "").split(",") if v]:
+        S, T = (int(x) for x in shape.split("x"))
+        src = sphere(100000).to(dev)[:S].contiguous()
+        tgt_idx = torch.randperm(100000, generator=torch.Generator().manual_seed(1))[:T].to(dev)
+        full = sphere(100000).to(dev)
+        out = torch.empty(T, 3, device=dev)
+        ws = {k: torch.empty(lib.dnp_field_grad_workspace_bytes(S, T, 15000), dtype=torch.uint8, device=dev) for k, lib in libs.items()}
+        times = {k: [] for k in libs}
+        for rnd in range(24):
+            for name in (list(libs) if rnd % 2 == 0 else list(libs)[::-1]):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                rc = libs[name].dnp_field_grad_f32(_lib.ptr(src), S, 6, None, _lib.ptr(full), T, 6, _lib.ptr(tgt_idx), 1e-5, 15000, _lib.ptr(out),
+                                                   3, 0, 0, None, None, _lib.ptr(ws[name]), ws[name].numel(), stream)
+                b.record()
+                torch.cuda.synchronize()
+                assert rc == 0
+                if rnd >= 4:
+                    times[name].append(a.elapsed_time(b))
+        for name, ts in times.items():
+            ts = np.array(ts) * 1e3
+            print(f"{shape:14s} {name:12s} median {np.median(ts):9.1f} us  min {ts.min():9.1f}  ({S * T / np.median(ts) / 1e3:7.1f} Gpairs/s)", flush=True)
     only = [c for c in os.environ.get("K1_CLOUDS", "").split(",") if c]
     for cname, pc in clouds.items():
         if only and cname not in only:

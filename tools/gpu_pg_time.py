@@ -25,7 +25,7 @@ for item in [v for v in os.environ.get("PG_VARIANTS", "").split(";") if v]:
 dev = torch.device("cuda:0")
 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 g = torch.Generator().manual_seed(1)
-for P in (72, 256, 512, 1024, 2048, 4096, 8192, 16384):
+for P in (72, 128, 256, 369, 512, 700, 1024, 1500, 2048, 4096, 8192, 16384):
     W0 = torch.randn(P, P, generator=g, dtype=torch.float64).to(dev)
     W = torch.empty_like(W0)
     start = torch.zeros(1, dtype=torch.int64, device=dev)
