@@ -38,9 +38,11 @@ Also printed on the same JSON line:
                 box's host cores on a bounded sample (rank 0, N = 1 only).
 """
 import argparse
+import datetime
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -53,7 +55,44 @@ from tools.workloads import N_PATCHES, N_POINTS, fibonacci_patches, headline_wor
 
 FLOP_PER_PAIR = 33            # 3 sub, 5 r.r, 5 p.r, sqrt, 2 fma (4), rcp, 2 mul, 12 accumulate
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md (= the dense f32 MFMA peak)
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md; v_fma_f64 measured at 4.3 cycles per wave64 instruction (profiles/r05_ubench_f64.txt)
 HBM_PEAK_GBS = 8000.0
+# a rank that dies must not leave the others hanging until the driver's limit (round-4 verdict); the rehearsal shortens it
+COLLECTIVE_TIMEOUT_S = float(os.environ.get("BENCH_COLLECTIVE_TIMEOUT_S", "120"))
+DEADLINE_S = float(os.environ.get("BENCH_DEADLINE_S", "900"))   # host-side deadline of the whole run
+
+
+class Deadline:
+    """Host-side watchdog: if the run is not finished `seconds` after start (a hung collective, a dead peer), rank 0 prints ONE
+    JSON line carrying "error" - so the driver records a failure with its cause instead of a silence - every rank says so on
+    stderr, and the process ends with a fresh non-zero exit (os._exit: no exec, no atexit handlers that could touch the GPU)."""
+
+    def __init__(self, seconds, rank, world):
+        self.rank, self.world, self.seconds = rank, world, seconds
+        self.phase = "start"
+        self.timer = threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def _fire(self):
+        msg = f"bench.py rank {self.rank} of {self.world}: not finished after {self.seconds:.0f} s (phase: {self.phase})"
+        print(msg, file=sys.stderr, flush=True)
+        if self.rank == 0:
+            print(json.dumps({"metric": "dipole field-evals/sec (N x N pairs), 100k pts", "value": None, "unit": "pairs/s",
+                              "n_gpus": self.world, "error": msg}), flush=True)
+        os._exit(3)
+
+    def cancel(self):
+        self.timer.cancel()
+
+
+def fail(rank, world, msg):
+    """A wrong result is a failed run: rank 0 prints the JSON line with "error", every rank exits non-zero."""
+    print(f"bench.py rank {rank}: {msg}", file=sys.stderr, flush=True)
+    if rank == 0:
+        print(json.dumps({"metric": "dipole field-evals/sec (N x N pairs), 100k pts", "value": None, "unit": "pairs/s",
+                          "n_gpus": world, "error": msg}), flush=True)
+    os._exit(4)
 
 
 def cpu_baseline(pc_cpu, seconds_target=15.0):
@@ -166,6 +205,22 @@ def other_configs(dev, fu, util, pts_sorted, patch_ranges):
     t = timed(lambda: fu.reference_field(pts_sorted, tgt), 5)
     out["config5_reference_field_100k_to_100k"] = {"sources": N_POINTS, "targets": N_POINTS, "ms": t * 1e3,
                                                    "pairs_per_s": float(N_POINTS) ** 2 / t, "dtype": "f32"}
+    # ---- the float64 entry points (round 5; the reference's socket path hands float64 clouds to the same functions): pairs/s
+    # and the fraction of the FP64 vector peak at the 33 flop per pair of the fp32 roofline
+    def f64_leg(pairs, t):
+        return {"ms": t * 1e3, "pairs_per_s": pairs / t, "dtype": "f64",
+                "frac_of_fp64_valu_peak": pairs * FLOP_PER_PAIR / t / 1e12 / FP64_VALU_PEAK_TFLOPS}
+    grid = util.gen_grid().to(dev)
+    t = timed(lambda: fu.potential(pts_sorted, grid), 20)
+    out["potential_100k_x_1000_lattice"] = {"ms": t * 1e3, "pairs_per_s": float(N_POINTS) * grid.shape[0] / t, "dtype": "f32"}
+    pts64, tgt64, grid64 = pts_sorted.double(), tgt.double(), grid.double()
+    out["potential_100k_x_1000_lattice_f64"] = f64_leg(float(N_POINTS) * grid.shape[0], timed(lambda: fu.potential(pts64, grid64), 20))
+    out["allpairs_100k_field_grad_f64"] = f64_leg(float(N_POINTS) ** 2, timed(lambda: fu.field_grad(pts64, pts64), 3))
+    out["config5_reference_field_100k_to_100k_f64"] = f64_leg(float(N_POINTS) ** 2, timed(lambda: fu.reference_field(pts64, tgt64), 3))
+    t = timed(lambda: fu.strongest_field_propagation(pts64.clone(), list(enumerate(patch_ranges)), patch_ranges, diffuse=True), 3)
+    out["config4_patch_driver_end_to_end_f64"] = dict(f64_leg(float(N_POINTS) ** 2, t), points=N_POINTS, patches=N_PATCHES,
+                                                      note="float64 cloud: fp64 slabs, W, combine and tail (dnp_patch_fields_tiled_f64 ...)")
+    del pts64, tgt64, grid64
     # the same two calls with HOST tensors in and out (the reference's functions take either): H2D + D2H of the cloud
     # over PCIe inside the timed call.  Never the headline value (inputs resident in HBM there) - DESIGN.md section 5.
     host = pts_sorted.cpu()       # oriented in place call after call (a torch CPU clone of 2.4 MB inside the timed loop costs
@@ -206,15 +261,23 @@ def main():
     # BENCH_ONE_RANK_RCCL=1 (one GPU, no launcher): a ONE-rank nccl group, so that the pipelined loop's asynchronous all-gather
     # runs through RCCL itself on a single-GPU box (rehearsal of that code path; the line says "rehearsal")
     one_rank_rccl = world == 1 and bool(os.environ.get("BENCH_ONE_RANK_RCCL"))
+    deadline = Deadline(DEADLINE_S, rank, world)
+    deadline.phase = "init_process_group"
+    ctimeout = datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S)     # instead of the default 10 minutes per collective
     if world > 1:
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=ctimeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=ctimeout)
     elif one_rank_rccl:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=ctimeout)
+    if world > 1 and os.environ.get("BENCH_TEST_DIE_RANK") == str(rank):
+        # rehearsal hook (tools/rehearse.sh): this rank leaves before its first collective - the others must end with an
+        # "error" line within the collective timeout, not hang
+        print(f"bench.py rank {rank}: BENCH_TEST_DIE_RANK set, leaving", file=sys.stderr, flush=True)
+        os._exit(7)
 
     from dipole_normal_prop_amd import field_utils as fu
     from dipole_normal_prop_amd import parallel, util
@@ -238,7 +301,7 @@ def main():
         fb = fu._balanced_blocks(sizes, fake)
         p_lo, p_hi = int(fb[0]), int(fb[1])
     my_pairs = float((sizes[p_lo:p_hi] * (N_POINTS - sizes[p_lo:p_hi])).sum())
-    split = fu._pick_source_split(sizes[p_lo:p_hi], N_POINTS)     # the drivers' rule: short launches split their items
+    split, groups = fu._pick_source_split(sizes[p_lo:p_hi], N_POINTS)     # the drivers' rule: short launches split their items
     # The headline step gathers in the launch stream's order (what the product's driver does).  At N > 1 over RCCL a second
     # timed loop overlaps the all-gather with the next step's pair kernel (BENCH_NO_PIPELINED=1 skips it; BENCH_PIPELINED=1
     # forces it on other backends / one rank, where gather_rows_async falls back to the in-order form).
@@ -255,9 +318,9 @@ def main():
             marks[0].record()
         if tiles.fused:              # what the drivers do (field_utils._slabs_and_rows), opened up for the event marks
             w_part = torch.empty((p_hi - p_lo, tiles.n_tiles, tiles.slots), dtype=torch.float64, device=dev)
-            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part, split)
+            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part, split, groups)
         else:
-            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, None, split)
+            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, None, split, groups)
         if marks is not None:
             marks[1].record()
         if tiles.fused:
@@ -298,6 +361,60 @@ def main():
             dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
+    def check_against_g19(Wfull):
+        """The greedy loop on the gathered matrix against the REFERENCE's own run on this cloud (tests/golden/G19: visit order, flips
+        and chosen interactions of field_utils.strongest_field_propagation, start patch = the reference's), and the patch
+        scramble undone: every scrambled patch ends with one sign, every untouched patch with the other."""
+        g19_path = os.path.join(ROOT, "tests", "golden", "G19_headline_sphere_patch_propagation.npz")
+        g19 = np.load(g19_path) if os.path.exists(g19_path) else None
+        start = int(g19["order"][0]) if g19 is not None else 0
+        order, sigma, chosen = fu._greedy_on_device(Wfull, torch.full((1,), start, dtype=torch.int64, device=dev))
+        sigma = sigma.cpu().numpy()
+        flipped_sign, kept_sign = sigma[scramble], sigma[~scramble]
+        s_ok = bool(np.all(flipped_sign == flipped_sign[0]) and np.all(kept_sign == kept_sign[0]) and flipped_sign[0] == -kept_sign[0])
+        t_ok = c_dev = None
+        if g19 is not None:
+            order = order.cpu().numpy()
+            t_ok = bool(np.array_equal(order, g19["order"]) and np.array_equal(sigma[order[1:]] < 0, g19["flipped"][1:]))
+            c_dev = float(np.max(np.abs(chosen.cpu().numpy() - g19["chosen"]) / np.abs(g19["chosen"])))
+        return s_ok, t_ok, c_dev
+
+    # ---- before anything is timed (N > 1; round-4 verdict: the first run with more than one RCCL rank must not be trusted
+    # blindly): every rank's rows of the gathered matrix are the rows it computed, the matrix reproduces the reference's trace,
+    # and every rank answered the collective
+    precheck = None
+    if world > 1 or one_rank_rccl:
+        deadline.phase = "precheck (first collectives)"
+        torch.cuda.synchronize()
+        w_part0 = torch.empty((p_hi - p_lo, tiles.n_tiles, tiles.slots), dtype=torch.float64, device=dev) if tiles.fused else None
+        dE0 = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part0, split, groups)
+        if tiles.fused:
+            W_local = torch.empty((p_hi - p_lo, N_PATCHES), dtype=torch.float64, device=dev)
+            fu._lib.check(fu._lib.require_device().dnp_interactions_from_tiles(
+                fu._lib.ptr(w_part0), tiles.slots, p_hi - p_lo, N_POINTS, fu._lib.ptr(point_patch), fu._lib.ptr(off), N_PATCHES,
+                fu._lib.ptr(W_local), fu._lib.current_stream()))
+        else:
+            W_local = fu._interaction_rows(dE0, pts, off, idx)
+        del dE0
+        Wg = parallel.gather_rows(W_local, bounds)
+        rows_ok = tuple(Wg.shape) == (N_PATCHES, N_PATCHES) and bool(torch.equal(Wg[p_lo:p_hi], W_local))
+        s_ok, t_ok, _ = check_against_g19(Wg) if rows_ok else (False, False, None)
+        cpu_side = not (world > 1 and backend == "nccl")
+        flags = torch.tensor([1 if rows_ok else 0, 1 if (s_ok and t_ok is not False) else 0], dtype=torch.int32, device="cpu" if cpu_side else dev)
+        seen = torch.zeros(max(world, 1), dtype=torch.int32, device="cpu" if cpu_side else dev)
+        seen[rank] = 1
+        if world > 1:
+            dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+            dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        precheck = {"gathered_rows_equal_local_rows_on_every_rank": bool(int(flags[0].item())),
+                    "trace_matches_reference_G19_on_every_rank": bool(int(flags[1].item())),
+                    "ranks_seen": int((seen > 0).sum().item())}
+        if not (precheck["gathered_rows_equal_local_rows_on_every_rank"] and precheck["trace_matches_reference_G19_on_every_rank"]
+                and precheck["ranks_seen"] == max(world, 1)):
+            fail(rank, world, f"pre-check of the gathered interaction matrix failed: {precheck}")
+        del Wg, W_local, w_part0
+    deadline.phase = "warm-up"
+
     # Clock ramp: after an idle phase the first ~40-60 ms of GPU work run up to 25 % slower (the device climbs to its
     # sustained clock under load; profiles/r02_kernel_trace_durations.txt, and for an eighth-size step 30 launches after 20
     # warm-up launches still fall from 0.66 to 0.57 ms).  The W warm-up steps cover that at N = 1 (10 x 4.1 ms); at N ranks a
@@ -329,6 +446,7 @@ def main():
         detail = world > 1 or i % 4 == 0
         return [torch.cuda.Event(enable_timing=True) if (j < 2 or detail) else None for j in range(4)]
     ev = [marks_for(i) for i in range(args.steps)]
+    deadline.phase = "timed steps"
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -345,6 +463,7 @@ def main():
     # ---- the same steps with the all-gather overlapped (N > 1 over RCCL): reported beside the headline, never as it ---
     pipelined = None
     if can_pipeline:
+        deadline.phase = "pipelined steps (asynchronous all-gather)"
         overlap_state["on"] = True
         for _ in range(max(args.warmup, 4)):
             W = step()
@@ -429,22 +548,11 @@ def main():
     trace_matches_reference = chosen_dev = None
     if not (fake > 1 and world == 1):
         assert W.shape == (N_PATCHES, N_PATCHES)
-        g19_path = os.path.join(ROOT, "tests", "golden", "G19_headline_sphere_patch_propagation.npz")
-        g19 = np.load(g19_path) if os.path.exists(g19_path) else None
-        start = int(g19["order"][0]) if g19 is not None else 0
-        order, sigma, chosen = fu._greedy_on_device(W, torch.full((1,), start, dtype=torch.int64, device=dev))
-        sigma = sigma.cpu().numpy()
-        flipped_sign, kept_sign = sigma[scramble], sigma[~scramble]
-        signs_ok = bool(np.all(flipped_sign == flipped_sign[0]) and np.all(kept_sign == kept_sign[0])
-                        and flipped_sign[0] == -kept_sign[0])
-        if g19 is not None:
-            order = order.cpu().numpy()
-            trace_matches_reference = bool(
-                np.array_equal(order, g19["order"]) and np.array_equal(sigma[order[1:]] < 0, g19["flipped"][1:]))
-            chosen_dev = float(np.max(np.abs(chosen.cpu().numpy() - g19["chosen"]) / np.abs(g19["chosen"])))
+        signs_ok, trace_matches_reference, chosen_dev = check_against_g19(W)
 
     # ---- N > 1: the whole product call, every rank in it (what a caller of parallel.sharded_patch_propagation gets) ------
     sharded_driver = None
+    deadline.phase = "sharded driver leg / other configs"
     if world > 1 and not args.headline_only:
         ranges = util.PatchList(torch.arange(N_POINTS, device=dev), sizes, disjoint=True)
         plist = list(enumerate(ranges))
@@ -489,6 +597,11 @@ def main():
                "trace_matches_reference_G19": trace_matches_reference, "chosen_max_rel_dev_vs_G19": chosen_dev}
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if precheck is not None:
+            # checked BEFORE the timed steps: a failure there ends the run with an "error" line instead of a number
+            out["precheck"] = precheck
+            out["rccl_ranks_seen" if backend == "nccl" else "ranks_seen"] = precheck["ranks_seen"]
+        out["collective_timeout_s"] = COLLECTIVE_TIMEOUT_S if (world > 1 or one_rank_rccl) else None
         if pipelined is not None:
             # NOT the headline: the step with its all-gather overlapped with the next step's pair kernel - what a caller that
             # hands parallel.sharded_patch_propagation_many several clouds reaches; one cloud at a time cannot (the greedy
@@ -516,12 +629,25 @@ def main():
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         fu.flush_warnings()
         print(json.dumps(out), flush=True)
+    deadline.phase = "shutdown"
     if world > 1:
         dist.barrier(device_ids=[dev_index]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
     elif one_rank_rccl:
         dist.destroy_process_group()
+    deadline.cancel()
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as exc:      # a collective that timed out, a peer that died, a failed launch: say so on the JSON line
+        import traceback
+        traceback.print_exc()
+        _rank, _world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        if _rank == 0:
+            print(json.dumps({"metric": "dipole field-evals/sec (N x N pairs), 100k pts", "value": None, "unit": "pairs/s",
+                              "n_gpus": _world, "error": f"{type(exc).__name__}: {exc}"[:2000]}), flush=True)
+        os._exit(5)

@@ -472,9 +472,8 @@ def test_source_split_does_not_change_a_bit(dev):
     assert sizes.min() > 128 and sizes.max() <= 512
     point_patch = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
     boxes, tiles = fu._patch_boxes(swork, off, None), fu._TileTables(swork, sizes)
-    assert fu._pick_source_split(sizes[:16], N) == -3 and fu._pick_source_split(sizes[:32], N) == -3
-    assert fu._pick_source_split(sizes[:128], N) == -3 and fu._pick_source_split(sizes, N) == 1
-    assert fu._pick_source_split(np.array([100, 300]), N) == 1 and fu._pick_source_split(np.array([300, 600]), N) == 1
+    assert fu._pick_source_split(sizes[:16], N) == (-3, 1) and fu._pick_source_split(sizes[:32], N) == (-3, 1)
+    assert fu._pick_source_split(sizes[:128], N) == (-3, 1) and fu._pick_source_split(sizes, N) == (1, 1)
     res = {}
 
     def poison(shape):       # _patch_slabs returns torch.empty memory: make sure a launch that wrote nothing cannot pass on stale rows
@@ -499,13 +498,13 @@ def test_source_split_does_not_change_a_bit(dev):
     for k in (5, 2):
         dEr = torch.full((24, N, 3), float("nan"), dtype=torch.float32, device=dev)
         rc = lib.dnp_patch_fields_tiled_f32(_lib.ptr(swork), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch), _lib.ptr(boxes),
-                                            _lib.ptr(tiles.boxes), 40, 64, 1e-5, _lib.ptr(dEr), None, 2, -k, _lib.ptr(own), nb,
+                                            _lib.ptr(tiles.boxes), 40, 64, 1e-5, _lib.ptr(dEr), None, 2, -k, 1, _lib.ptr(own), nb,
                                             _lib.current_stream())
         assert rc == 0 and torch.equal(dEr, res[1][0]), k
     # a split launch without the buffer is refused, not run wrong
     dE = torch.empty((24, N, 3), dtype=torch.float32, device=dev)
     rc = _lib.load().dnp_patch_fields_tiled_f32(_lib.ptr(swork), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch), _lib.ptr(boxes),
-                                                _lib.ptr(tiles.boxes), 40, 64, 1e-5, _lib.ptr(dE), None, 2, -3, None, 0,
+                                                _lib.ptr(tiles.boxes), 40, 64, 1e-5, _lib.ptr(dE), None, 2, -3, 1, None, 0,
                                                 _lib.current_stream())
     assert rc == -3 and b"exchange buffer" in _lib.load().dnp_last_error()
     k = 51
@@ -524,9 +523,18 @@ def test_source_split_does_not_change_a_bit(dev):
     boxes2, tiles2 = fu._patch_boxes(sw2, off2, None), fu._TileTables(sw2, sizes2)
     a = fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, None, 1)
     for tail in (-1, -2, -4, -9, -10, -50, -3):
-        poison(tuple(a.shape))
-        b = fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, None, tail)
-        assert torch.equal(a, b), tail
+        for groups in (1, 2):         # 2 (round 5): eight wavefronts per split item - the 513- and 900-point patches are split too
+            poison(tuple(a.shape))
+            b = fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, None, tail, groups)
+            assert torch.equal(a, b), (tail, groups)
+    # ... with the interaction partials, two and three group slots (the 64- / 41-point patches put three groups into a tile)
+    assert tiles2.slots == 3
+    wa = torch.full((len(sizes2), tiles2.n_tiles, 3), float("nan"), dtype=torch.float64, device=dev)
+    fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, wa, 1)
+    for tail, groups in ((-4, 2), (-50, 2), (-3, 1)):
+        wb = torch.full_like(wa, float("nan"))
+        b = fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, wb, tail, groups)
+        assert torch.equal(a, b) and torch.equal(wa, wb), (tail, groups)
     for k in (1, 2, 5, 9):
         lo, hi = int(off2[k]), int(off2[k + 1])
         others = (pp2 != k).cpu()

@@ -16,9 +16,19 @@ import json
 b=json.load(open('gpurun_out/rehearsal_line_$N.json'))
 print('# keys: value', b['value'], 'ms_per_step', b['ms_per_step'], '| value_pipelined', b.get('value_pipelined'), 'ms_per_step_pipelined', b.get('ms_per_step_pipelined'), 'pipelined_matches_in_order', b.get('pipelined_matches_in_order'), '|', b.get('pipelined_note'))
 print('# sharded_driver', b.get('sharded_driver'))
-print('# signs_ok', b['signs_ok'], 'trace_matches_reference_G19', b['trace_matches_reference_G19'])" >> $OUT
+print('# signs_ok', b['signs_ok'], 'trace_matches_reference_G19', b['trace_matches_reference_G19'], '| precheck', b.get('precheck'), 'collective_timeout_s', b.get('collective_timeout_s'))" >> $OUT
   echo >> $OUT
 done
+# a peer that dies before its first collective: rank 0 must end with an "error" line within the (shortened) collective timeout
+echo "## BENCH_TEST_DIE_RANK=1 BENCH_COLLECTIVE_TIMEOUT_S=15: --nproc-per-node 2 (gloo), rank 1 leaves before its first collective" >> $OUT
+T0=$(date +%s)
+BENCH_BACKEND=gloo BENCH_TEST_DIE_RANK=1 BENCH_COLLECTIVE_TIMEOUT_S=15 timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29507 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --headline-only 2>gpurun_out/rehearsal_err_die.txt | grep '^{' | cut -c1-600 >> $OUT
+echo "# exit after $(( $(date +%s) - T0 )) s" >> $OUT
+# the host-side deadline: a run that cannot finish in time ends with an "error" line and a non-zero exit
+echo "## BENCH_DEADLINE_S=3 python bench.py (one GPU): the watchdog fires" >> $OUT
+BENCH_DEADLINE_S=3 timeout -k 10 100 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{' | cut -c1-400 >> $OUT
+echo "# exit code ${PIPESTATUS[0]}" >> $OUT
+echo >> $OUT
 S=gpurun_out/rank_share.txt
 : > $S
 for N in 1 2 4 8; do
