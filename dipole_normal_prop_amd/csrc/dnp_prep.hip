@@ -191,13 +191,20 @@ __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restri
 #endif
     if (DNP_PG_PRETOUCH && (int64_t)P * P * 8 <= (2 << 20)) {
         // W was written by other CUs a moment ago: a row load of the loop is served by the memory-side cache (~230 ns) until this
-        // XCD's L2 has the line (~85 ns).  One pass over the matrix puts all of it there.
-        const double2* w2 = reinterpret_cast<const double2*>(W);
-        const int64_t n2 = (int64_t)P * P / 2;
+        // XCD's L2 has the line (~85 ns).  One pass over the matrix puts all of it there.  (16-byte loads when W is 16-byte
+        // aligned - the ABI promises a const double*, i.e. 8 -, 8-byte loads otherwise; the sums only keep the loads alive.)
         double t = 0.0;
+        if ((reinterpret_cast<uintptr_t>(W) & 15) == 0) {
+            const double2* w2 = reinterpret_cast<const double2*>(W);
+            const int64_t n2 = (int64_t)P * P / 2;
 #pragma unroll 16
-        for (int64_t i = lane; i < n2; i += 64) { const double2 v = w2[i]; t += v.x + v.y; }
-        if (t == 1.2345e300) order_s[0] = -1;            // never true: keeps the loads
+            for (int64_t i = lane; i < n2; i += 64) { const double2 v = w2[i]; t += v.x + v.y; }
+        } else {
+            const int64_t n1 = (int64_t)P * P;
+#pragma unroll 16
+            for (int64_t i = lane; i < n1; i += 64) t += W[i];
+        }
+        asm volatile("" ::"v"(t));                       // a sink: the loads stay, nothing is stored
     }
     double s = 1.0;                                       // the start patch is not flipped
     for (int step = 0; step < P; ++step) {

@@ -49,6 +49,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// experiment switches that produce WRONG or UNSAFE kernels may only be combined with the check build (round-4 advisor)
+#if defined(DNP_BUG_A8D48F5) && !defined(DNP_BOUNDS)
+#error "DNP_BUG_A8D48F5 re-enables the out-of-bounds tile_box read of round 3: only together with -DDNP_BOUNDS (tests/test_gpu_bounds.py)"
+#endif
+#if defined(DNP_SKIP_REDUCE) && !defined(DNP_EXPERIMENT)
+#error "DNP_SKIP_REDUCE drops the second pass of field_grad (wrong results): timing experiments only, pass -DDNP_EXPERIMENT with it"
+#endif
+
 namespace dnp {
 
 #ifdef DNP_STAMP   // timeline builds only (tools/gpu_timeline.py); the product library has none of this.  Every

@@ -568,10 +568,18 @@ def _patch_boxes(work: torch.Tensor, off, idx) -> torch.Tensor:
     return boxes
 
 
+# exchange buffers up to this size stay cached per (thread, device, stream); a larger one (24 704 bytes per split patch and
+# 128-row tile: 58 MB for 3 split patches at 100 000 points, 580 MB at a million) is allocated zeroed for the call and freed
+EXCHANGE_CACHE_MAX_BYTES = 256 << 20
+
+
 def _exchange(nbytes: int, dev: torch.device) -> torch.Tensor:
     """Exchange buffer of the split forms (include/dnp.h, dnp_patch_fields_tiled_f32): zero at its first use, left zero
     by every launch that uses it; cached per (thread, device, stream) like the workspace, because one buffer serves one
-    stream at a time."""
+    stream at a time.  A launch that FAILS may leave arrival counters behind: _exchange_drop forgets the cached buffer then
+    (round-4 advisor), the next call gets a fresh zeroed one."""
+    if nbytes > EXCHANGE_CACHE_MAX_BYTES:
+        return torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     cache = getattr(_tls, "xch", None)
     if cache is None:
         cache = _tls.xch = {}
@@ -580,6 +588,12 @@ def _exchange(nbytes: int, dev: torch.device) -> torch.Tensor:
     if buf is None or buf.numel() < nbytes:
         buf = cache[key] = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
     return buf
+
+
+def _exchange_drop(dev: torch.device) -> None:
+    cache = getattr(_tls, "xch", None)
+    if cache is not None:
+        cache.pop((dev.index, torch.cuda.current_stream(dev).cuda_stream), None)
 
 
 def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, eps: float, boxes=None, tile_boxes=None,
@@ -612,6 +626,8 @@ def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, ep
                                             p0, p1, float(eps), _lib.ptr(dE), _lib.ptr(w_part),
                                             2 if w_part is None else int(w_part.shape[-1]), int(source_split), int(split_groups),
                                             _lib.ptr(xch), xch_bytes, _lib.current_stream())
+    if rc != 0 and xch is not None:
+        _exchange_drop(work.device)               # its counters may not be re-armed: never reuse it
     _lib.check(rc)
     return dE
 

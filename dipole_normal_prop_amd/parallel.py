@@ -143,10 +143,11 @@ def sharded_patch_propagation(pts: torch.Tensor, patches, all_patches, diffuse=F
         _finish_sharded(fu, pts, work, w, st, patches, diffuse, listed, start_t)
 
 
-def sharded_patch_propagation_many(jobs, diffuse=False):
+def sharded_patch_propagation_many(jobs, diffuse=False, force_async=False):
     """sharded_patch_propagation for SEVERAL clouds, pipelined: `jobs` is a sequence of (pts, patches, all_patches) or
     (pts, patches, all_patches, weights, start_patch) tuples, every rank passes the same sequence, every `pts` is oriented in
-    place.  Returns the list of traces (order / sigma / chosen / start as numpy arrays), one per job.
+    place.  Returns the list of traces (order / sigma / chosen / start as numpy arrays), one per job IN THE JOBS' ORDER - None
+    for a job without patches (nothing to propagate), so the list lines up with the caller's jobs.
 
     One cloud cannot hide its all-gather - the greedy loop needs all of W - but a queue of clouds can: the W rows of cloud
     i are gathered on the collective library's own stream (gather_rows_async) while this rank's pair kernel of cloud i + 1
@@ -154,11 +155,11 @@ def sharded_patch_propagation_many(jobs, diffuse=False):
     ONE broadcast up front (a per-job broadcast would queue behind the asynchronous gather of the next job and pull it onto
     the critical path); the diffuse form's all-reduce of the partial fields stays in stream order.  Results are those of
     sharded_patch_propagation job by job (bit for bit); where the backend stages through the host (gloo) or blocks are
-    unequal, the gather falls back to the in-order form and only the launch order differs."""
+    unequal, the gather falls back to the in-order form and only the launch order differs.  force_async: take the
+    asynchronous path with a ONE-rank group too (the rehearsal of that path on a one-GPU box; tests)."""
     from . import field_utils as fu
 
     rank, size = world()
-    traces = []
     with torch.no_grad():
         norm = []
         for job in jobs:
@@ -166,7 +167,9 @@ def sharded_patch_propagation_many(jobs, diffuse=False):
             weights = job[3] if len(job) > 3 else None
             start_patch = job[4] if len(job) > 4 else None
             norm.append((pts, patches, all_patches, weights, start_patch))
-        live = [j for j in norm if len(j[2]) > 0]
+        live_ids = [i for i, j in enumerate(norm) if len(j[2]) > 0]
+        live = [norm[i] for i in live_ids]
+        traces = [None] * len(norm)
         if not live:
             return traces
         prepared = [fu._prepare_work(pts, weights) for pts, _, _, weights, _ in live]
@@ -184,12 +187,12 @@ def sharded_patch_propagation_many(jobs, diffuse=False):
             st = fu._batched_end(bw, W, start_t)
             listed = fu._listed_patches(patches, all_patches, work.device) if diffuse else None
             _finish_sharded(fu, pts, work, w, st, patches, diffuse, listed, start_t)
-            traces.append(fu.last_trace("sharded"))
+            traces[live_ids[i]] = fu.last_trace("sharded")
 
         pending = None
         for i, (pts, patches, all_patches, _, _) in enumerate(live):
             bw = fu._batched_begin(prepared[i][0], all_patches, diffuse, rank=rank, world=size)
-            W, handle = gather_rows_async(bw.W_local, bw.bounds)
+            W, handle = gather_rows_async(bw.W_local, bw.bounds, force=force_async)
             if pending is not None:
                 finish(pending)
             pending = (i, bw, W, handle)

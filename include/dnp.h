@@ -186,7 +186,8 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts,
  * than 512 * split_groups points is evaluated by one wavefront per tile, patches of <= 128 points are a single run.
  * dE and w_part do not depend on source_split or split_groups (the same fp32 runs, the same fp64 additions in run order);
  * without both tables a launch with source_split < 0 is the plain one.
- * exchange: device scratch of at least dnp_patch_exchange_bytes(N, k) bytes (NULL / 0 with source_split = 1).  CONTRACT: the
+ * exchange: device scratch of at least dnp_patch_exchange_bytes(N, k) bytes = k * ceil(N / 128) * 24 704 (a 128-byte counter
+ * line + 8 run slots x 6 doubles x 64 lanes per split (patch, tile) item; NULL / 0 with source_split = 1).  CONTRACT: the
  * buffer is zero before its first use (dnp_exchange_init, or any memset); every launch leaves its arrival counters zero
  * again, and a record's place in the buffer depends on its (patch, tile) index only, so one buffer serves launches of any
  * size one after the other - on ONE stream at a time.  A launch with source_split < 0 and no (or too small a) buffer

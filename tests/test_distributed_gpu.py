@@ -201,3 +201,66 @@ def test_many_clouds_pipelined_on_the_device_equal_the_single_calls(dev):
             assert np.array_equal(tr["order"], g[f"order_{tag}"]), tag
             assert np.array_equal((tr["sigma"] < 0)[tr["order"]], g[f"flipped_{tag}"]), tag
             assert torch.equal(job[0], one), tag
+
+
+def _one_rank_rccl_worker(port, q):
+    """A process of its own with a ONE-rank nccl group (all a one-GPU box allows): the asynchronous RCCL path of
+    sharded_patch_propagation_many - all_gather_into_tensor(async_op=True) on RCCL's stream under the next cloud's pair kernel,
+    interleaved with the diffuse form's all-reduce - against the single calls."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from dipole_normal_prop_amd import field_utils as fu
+        from dipole_normal_prop_amd import parallel
+        g = load_golden("G6_patch_propagation")
+        allp = [p.to(dev) for p in csr_to_list(g["patch_off"], g["patch_idx"])]
+        patches = [(int(i), allp[int(i)]) for i in g["filtered"]]
+        seen = {"async": 0}
+        real = parallel.gather_rows_async
+
+        def spy(*a, **k):
+            W, work = real(*a, **k)
+            seen["async"] += work is not None
+            return W, work
+        parallel.gather_rows_async = spy
+        ok = True
+        for dflag in ("n", "d"):
+            tags = [t for t in ALL_G6 if t.split("_")[1] == dflag]
+            jobs, singles = [], []
+            for tag in tags:
+                cname, _, wflag = tag.split("_")
+                cloud = torch.from_numpy(g["pc_patchflip"] if cname == "pf" else g["pc_scrambled"])
+                w = torch.from_numpy(g["weights"]).to(dev) if wflag == "w" else None
+                jobs.append((cloud.clone().to(dev), patches, allp, w))
+                one = cloud.clone().to(dev)
+                fu.strongest_field_propagation(one, patches, allp, diffuse=(dflag == "d"), weights=w)
+                singles.append(one)
+            jobs.insert(2, (torch.zeros(4, 6, device=dev), [], []))          # a job without patches: None in its place
+            traces = parallel.sharded_patch_propagation_many(jobs, diffuse=(dflag == "d"), force_async=True)
+            ok &= len(traces) == len(jobs) and traces[2] is None
+            del jobs[2], traces[2]
+            for tag, job, one, tr in zip(tags, jobs, singles, traces):
+                ok &= bool(np.array_equal(tr["order"], g[f"order_{tag}"])) and bool(torch.equal(job[0], one))
+        torch.cuda.synchronize()
+        q.put((ok, seen["async"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_many_clouds_through_the_asynchronous_rccl_gather_with_one_rank(dev):
+    """Round-4 advisor: the world > 1 asynchronous path of sharded_patch_propagation_many had no test (gloo and one process both
+    take the synchronous fallback).  A one-rank nccl group with force_async runs it through RCCL itself: eight asynchronous
+    gathers seen, every cloud equal to its single call, a job without patches answered with None in place."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_rccl_worker, args=(port, q))
+    p.start()
+    ok, n_async = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0 and ok and n_async == 8

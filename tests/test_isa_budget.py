@@ -55,3 +55,33 @@ def test_no_pair_kernel_needs_a_private_segment():
         if m.group(1).startswith("pair_kernel<float, double, 0, 1,") or m.group(1).startswith("pair_kernel<float, double, 1, 1,"):
             assert int(m.group(5)) == 8, line
     assert seen >= 24
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not found")
+def test_exchange_hand_off_is_write_through_stores_then_a_wait_then_the_ticket():
+    """Round-4 advisor: the split tail's hand-off uses relaxed agent-scope atomics only and is correct because of two target facts -
+    the run terms are stored write-through (sc1) and an s_waitcnt vmcnt(0) stands between them and the ticket's atomic add
+    (gfx9: vmcnt counts stores) - plus the last arriver's acquire (buffer_inv sc1) before it reads the terms back.  A compiler
+    change that drops any of the three would fail silently on the GPU; it fails here."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_resources.py"), "dnp_patch.hip"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = open("/tmp/isa/dnp_patch.hip.s").read()
+    names = re.findall(r"^(_ZN3dnp18pair_kernel_scalarIffLi0ELi2ELi0ELb1ELb1ELb1ELi\dELi4ELi4ELb1EEEvNS_8PairArgsIT_T0_EE):", text, flags=re.M)
+    assert len(set(names)) == 3, names                     # the exchange-tail kernel without partials and with 2 / 3 group slots
+    for name in set(names):
+        body = text[text.index(name + ":"):text.index(".end_amdhsa_kernel", text.index(name + ":"))]
+        lines = [ln.split(";")[0].strip() for ln in body.splitlines()]
+        lines = [ln for ln in lines if ln and not ln.startswith(".")]
+        # the ticket is the one atomic add that RETURNS a value (sc0); the others are the Inf / NaN counters of the direct epilogue
+        at = [i for i, ln in enumerate(lines) if ln.startswith("global_atomic_add") and ln.endswith("sc0")]
+        assert len(at) == 1, (name, at)
+        before = lines[:at[0]]
+        last_wait = max(i for i, ln in enumerate(before) if ln.startswith("s_waitcnt") and "vmcnt(0)" in ln)
+        stores = [i for i, ln in enumerate(before) if ln.startswith("global_store_dwordx2") and "sc1" in ln]
+        assert len(stores) >= 6 and max(stores) < last_wait, (name, stores[-3:], last_wait)     # 6 doubles per lane, all before the wait
+        assert not any(ln.startswith(("global_store", "global_load", "flat_")) for ln in before[last_wait:]), name
+        after = lines[at[0]:]
+        inv = [i for i, ln in enumerate(after) if ln.startswith("buffer_inv") and "sc1" in ln]
+        loads = [i for i, ln in enumerate(after) if ln.startswith("global_load_dwordx2") and "sc1" in ln]
+        assert inv and loads and min(inv) < min(loads), (name, inv[:2], loads[:2])
