@@ -41,6 +41,7 @@ import argparse
 import datetime
 import json
 import os
+import signal
 import sys
 import threading
 import time
@@ -263,6 +264,14 @@ def main():
     one_rank_rccl = world == 1 and bool(os.environ.get("BENCH_ONE_RANK_RCCL"))
     deadline = Deadline(DEADLINE_S, rank, world)
     deadline.phase = "init_process_group"
+    if world > 1 and rank == 0:
+        # torch.distributed.run answers a rank that failed by sending SIGTERM to the others: rank 0 then still leaves its line
+        def _terminated(signum, frame):
+            print(json.dumps({"metric": "dipole field-evals/sec (N x N pairs), 100k pts", "value": None, "unit": "pairs/s",
+                              "n_gpus": world, "error": f"terminated by the launcher (signal {signum}) in phase '{deadline.phase}': "
+                              "a peer rank failed or the run was cancelled"}), flush=True)
+            os._exit(6)
+        signal.signal(signal.SIGTERM, _terminated)
     ctimeout = datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S)     # instead of the default 10 minutes per collective
     if world > 1:
         if backend == "nccl":

@@ -741,15 +741,16 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
             // inside a patch the ids are dealt XCD-first: id = (8 j + x), tile = 8 (j / h) + x, runs WAVES (j % h) ..., with
             // h = SS / WAVES workgroups per tile - a tile's workgroups share an XCD and every XCD gets every kind of run.
             static_assert(SS % WAVES == 0, "XCH: whole workgroups per tile");
-            const unsigned kH = (unsigned)(SS / WAVES) * (unsigned)a.split_groups;   // workgroups per (chunk, tile) item
-            const unsigned n_t8 = (n_tiles + 7u) & ~7u;         // tiles padded to whole groups of 8 (the surplus ones exit)
+            static_assert(SS == WAVES, "XCH: one four-wavefront workgroup per run group");
+            const unsigned gsh = (unsigned)a.split_groups - 1u;  // workgroups per (chunk, tile) item = split_groups = 1 << gsh (1 or 2)
+            const unsigned n_t8 = ((n_tiles + 7u) & ~7u) << gsh; // tiles padded to whole groups of 8 (the surplus ones exit), x groups
             const unsigned c = b - unsplit_blocks;
-            const unsigned row = c / (n_t8 * kH);
-            const unsigned r = c - row * (n_t8 * kH);
+            const unsigned row = c / n_t8;
+            const unsigned r = c - row * n_t8;
             const unsigned j = r >> 3;
-            const unsigned tile = (j / kH) * 8u + (r & 7u);
+            const unsigned tile = (j >> gsh) * 8u + (r & 7u);
             if (tile >= n_tiles) return;
-            sp = (int)((j % kH) * WAVES) + wave;
+            sp = (int)((j & gsh) * WAVES) + wave;
             bx = tile;
             chunk = (int64_t)a.split_from + row;
             ktg = 1;
@@ -928,7 +929,12 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
         s = part_lo;
         part_end = part_hi;
     } else if constexpr (SS > 1) {
-        exchange = row_split && (s_end - s_begin) <= (int64_t)(XCH ? kXchSlots : SS) * run_len;
+        // (XCH: an item has SS * split_groups wavefronts, one run each - a longer chunk is left to wavefront 0; the wavefronts
+        // of a second group have nothing to do for a chunk of <= SS runs and leave without drawing a ticket)
+        exchange = row_split && (s_end - s_begin) <= (int64_t)(XCH ? SS * a.split_groups : SS) * run_len;
+        if constexpr (XCH) {
+            if (exchange && sp >= SS && (s_end - s_begin) <= (int64_t)SS * run_len) return;
+        }
         if (exchange) {
             s = s_begin + (int64_t)sp * run_len;
             part_end = (s + run_len < s_end) ? s + run_len : s_end;
@@ -1004,7 +1010,10 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
                 if ((tid & 63) == 0)
                     drawn = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 drawn = (unsigned)__builtin_amdgcn_readfirstlane((int)drawn);
-                if (drawn != (unsigned)(SS * a.split_groups - 1)) return;   // somebody else arrives last and finishes the item
+                // arrivals of this item: SS wavefronts for a chunk of <= SS runs (a second group's wavefronts have left above), 2 SS
+                // otherwise - from n_runs, not from a.split_groups (held in an SGPR down to here that argument took the kernel from
+                // 78 to 82 SGPRs, and above 80 a CU admits seven 256-thread workgroups instead of eight)
+                if (drawn != (unsigned)((n_runs > SS ? 2 * SS : SS) - 1)) return;   // somebody else arrives last and finishes the item
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if ((tid & 63) == 0)                                // re-armed for the next launch on this buffer
