@@ -310,7 +310,7 @@ def main():
         fb = fu._balanced_blocks(sizes, fake)
         p_lo, p_hi = int(fb[0]), int(fb[1])
     my_pairs = float((sizes[p_lo:p_hi] * (N_POINTS - sizes[p_lo:p_hi])).sum())
-    split, groups = fu._pick_source_split(sizes[p_lo:p_hi], N_POINTS)     # the drivers' rule: short launches split their items
+    split = fu._pick_source_split(sizes[p_lo:p_hi], N_POINTS)     # the drivers' rule: short launches split their items
     # The headline step gathers in the launch stream's order (what the product's driver does).  At N > 1 over RCCL a second
     # timed loop overlaps the all-gather with the next step's pair kernel (BENCH_NO_PIPELINED=1 skips it; BENCH_PIPELINED=1
     # forces it on other backends / one rank, where gather_rows_async falls back to the in-order form).
@@ -327,9 +327,9 @@ def main():
             marks[0].record()
         if tiles.fused:              # what the drivers do (field_utils._slabs_and_rows), opened up for the event marks
             w_part = torch.empty((p_hi - p_lo, tiles.n_tiles, tiles.slots), dtype=torch.float64, device=dev)
-            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part, split, groups)
+            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part, split)
         else:
-            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, None, split, groups)
+            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, None, split)
         if marks is not None:
             marks[1].record()
         if tiles.fused:
@@ -396,7 +396,7 @@ def main():
         deadline.phase = "precheck (first collectives)"
         torch.cuda.synchronize()
         w_part0 = torch.empty((p_hi - p_lo, tiles.n_tiles, tiles.slots), dtype=torch.float64, device=dev) if tiles.fused else None
-        dE0 = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part0, split, groups)
+        dE0 = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part0, split)
         if tiles.fused:
             W_local = torch.empty((p_hi - p_lo, N_PATCHES), dtype=torch.float64, device=dev)
             fu._lib.check(fu._lib.require_device().dnp_interactions_from_tiles(

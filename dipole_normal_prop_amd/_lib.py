@@ -43,8 +43,7 @@ SIGNATURES = {
     "dnp_patch_tile_rows": (_c_i64, []),
     "dnp_tile_boxes_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
     "dnp_patch_fields_tiled_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64,
-                                                  ctypes.c_float, _c_p, _c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_p, _c_sz,
-                                                  _c_p]),
+                                                  ctypes.c_float, _c_p, _c_p, ctypes.c_int, ctypes.c_int, _c_p, _c_sz, _c_p]),
     "dnp_patch_fields_tiled_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64,
                                                   ctypes.c_double, _c_p, _c_p, ctypes.c_int, _c_p]),
     "dnp_patch_exchange_bytes": (_c_sz, [_c_i64, _c_i64]),

@@ -246,15 +246,15 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts, cons
                                const float* patch_box, int64_t p_begin, int64_t p_end, float eps, float* dE,
                                void* stream) {
     return dnp_patch_fields_tiled_f32(pts, N, ld_pts, patch_off, patch_idx, P, point_patch, patch_box, nullptr, p_begin,
-                                      p_end, eps, dE, nullptr, 2, 1, 1, nullptr, 0, stream);
+                                      p_end, eps, dE, nullptr, 2, 1, nullptr, 0, stream);
 }
 
 // exchange buffer of the split forms: one record per (split patch, target tile) - the arrival counter in a 128-byte line of
-// its own, then kXchSlots = 8 run slots x 6 doubles x 64 lanes of run terms (pair_kernel.h, xch_item_bytes): 24 704 bytes per
-// item, split_patches * ceil(N / 128) items (58 MB for the drivers' 3 split patches at N = 100 000)
+// its own, then 4 runs x 6 doubles x 64 lanes of run terms (pair_kernel.h, xch_item_bytes): 12 416 bytes per item,
+// split_patches * ceil(N / 128) items (29 MB for 3 split patches at N = 100 000)
 size_t dnp_patch_exchange_bytes(int64_t N, int64_t split_patches) {
     if (N <= 0 || split_patches <= 0) return 0;
-    return (size_t)split_patches * (size_t)ceil_div(N, (int64_t)64 * kPatchScalarKT) * (size_t)xch_item_bytes(kXchSlots, kPatchScalarKT, 3);
+    return (size_t)split_patches * (size_t)ceil_div(N, (int64_t)64 * kPatchScalarKT) * (size_t)xch_item_bytes(4, kPatchScalarKT, 3);
 }
 
 int dnp_exchange_init(void* exchange, size_t bytes, void* stream) {
@@ -268,10 +268,9 @@ int dnp_exchange_init(void* exchange, size_t bytes, void* stream) {
 int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
                                const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
                                const float* patch_box, const float* tile_box, int64_t p_begin, int64_t p_end, float eps,
-                               float* dE, double* w_part, int w_slots, int source_split, int split_groups, void* exchange,
-                               size_t exchange_bytes, void* stream) {
+                               float* dE, double* w_part, int w_slots, int source_split, void* exchange, size_t exchange_bytes,
+                               void* stream) {
     clear_error();
-    DNP_REQUIRE(split_groups == 1 || split_groups == 2, "split_groups=%d (1: split patches of <= 512 points, 2: <= 1024)", split_groups);
     DNP_REQUIRE(!w_part || w_slots == 2 || w_slots == 3, "w_slots=%d (2 or 3 group slots per tile)", w_slots);
     DNP_REQUIRE(source_split == 1 || (source_split < 0 && source_split >= -65535),
                 "source_split=%d (1, or -k: the last k patches of the launch as split items)", source_split);
@@ -305,7 +304,7 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
             const int64_t n_tiles_b = ceil_div(N, (int64_t)64 * kPatchScalarKT);
             pa.bnd.n_chunk_off = P + 1; pa.bnd.n_chunk_box = patch_box ? P : 0; pa.bnd.n_tile_box = tile_box ? n_tiles_b : 0;
             pa.bnd.n_tgt_group = N; pa.bnd.n_w_part = w_part ? kn * n_tiles_b * w_slots : 0; pa.bnd.n_partial = kn * N * 3;
-            pa.bnd.n_xch_items = exchange ? (int64_t)(exchange_bytes / (size_t)xch_item_bytes(kXchSlots, kPatchScalarKT, 3)) : 0;
+            pa.bnd.n_xch_items = exchange ? (int64_t)(exchange_bytes / (size_t)xch_item_bytes(4, kPatchScalarKT, 3)) : 0;
             pa.bnd.n_src_rows = N; pa.bnd.err = bounds_err_buffer();
         }
 #endif
@@ -329,12 +328,10 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
                 }
                 constexpr int kW = kXchWaves;
                 // split part: per patch the tiles padded to a multiple of 8 (XCD-first numbering), 4 / kW workgroups per tile
-                const int64_t blocks = (K - tail) * ceil_div(n_tiles, (int64_t)kW) +
-                                       (int64_t)tail * ceil_div(n_tiles, (int64_t)8) * 8 * (4 / kW) * split_groups;
+                const int64_t blocks = (K - tail) * ceil_div(n_tiles, (int64_t)kW) + (int64_t)tail * ceil_div(n_tiles, (int64_t)8) * 8 * (4 / kW);
                 DNP_REQUIRE(blocks < ((int64_t)1 << 31), "the tail form's grid of %lld workgroups", (long long)blocks);
                 pa.split_from = (int)(K - tail);
                 pa.n_chunks = (int)K;
-                pa.split_groups = split_groups;
                 pa.xch_ticket = (unsigned int*)exchange;
                 pa.xch_terms = (double*)((char*)exchange + 128);
                 const dim3 tgrid((unsigned)blocks);

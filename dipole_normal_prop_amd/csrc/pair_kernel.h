@@ -130,14 +130,10 @@ constexpr int kUnroll = DNP_UNROLL;  // sources per inner-loop iteration (multip
 constexpr int kMaxChunks = 512;   // by-value chunk table entries per launch (2 KB of kernarg)
 // bytes of one record of the exchange buffer (PairArgs::xch_ticket): a 128-byte line for the arrival counter + the run terms
 constexpr int64_t xch_item_bytes(int ss, int kt, int nc) { return 128 + (int64_t)ss * kt * nc * 64 * (int64_t)sizeof(double); }
-// run-term slots of a record in the XCH form (round 5): a split item's chunk may have up to kXchSlots runs of 128 sources
-// (1024 points).  A launch whose split patches all have <= 4 runs gives an item ONE four-wavefront workgroup (round 4's
-// geometry); with PairArgs::split_groups = 2 an item gets TWO workgroups - wavefronts 0..7 on the runs 0..7, one slot each,
-// the last of the eight arrivers adds the slots in run order.  (A second run per wavefront instead - wavefront i on runs i
-// and i + 4 - put a second copy of the run loop into the kernel: 65-66 VGPRs, one wavefront per SIMD less for every item.)
-// Round 4 had 4 slots: chunks of more than 512 points - half of a reference-grid partition's patches - were left to one
-// wavefront and the drivers refused the tail for such launches.
-constexpr int kXchSlots = 8;
+// (Round 5 built a second form - records of 8 run slots, split items of patches with 513..1024 points evaluated by TWO
+// four-wavefront workgroups, the last of eight arrivers adding the slots in run order; bit-identical, fuzzed - and measured
+// it: never ahead of leaving such a patch to one wavefront, +9 % on launches whose split patches all fit four runs (the
+// second workgroups start, read their range and leave).  Not kept: profiles/r05_xch_eight_wavefronts.patch, r05_rank_share_partitions.txt.)
 
 enum PairMode { kField = 0, kPotential = 1 };
 
@@ -198,7 +194,6 @@ struct PairArgs {
     double* w_part;          // scalar kernel, WPART: [gridDim.y][ceil(T / (64 KT))][WPART] per-(slab, tile) interaction partials
     int split_from;          // scalar kernel, XCH: chunks [split_from, n) of the launch are evaluated with the source split
     int n_chunks;            // scalar kernel, XCH: chunks of the launch (its grid is 1-D)
-    int split_groups;        // scalar kernel, XCH: four-wavefront workgroups per split (chunk, tile) item: 1 (chunks of <= 4 runs) or 2 (<= 8)
     // XCH: the exchange buffer, one record per (split chunk, target tile) item: [arrival counter, padded to a 128-byte line]
     // [SS][KT * NC][64] run terms (fp64).  A record's place depends on the item's index only, so launches of any size keep
     // their counters in the same words: zero before the first launch, left zero by every launch.
@@ -741,16 +736,16 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
             // inside a patch the ids are dealt XCD-first: id = (8 j + x), tile = 8 (j / h) + x, runs WAVES (j % h) ..., with
             // h = SS / WAVES workgroups per tile - a tile's workgroups share an XCD and every XCD gets every kind of run.
             static_assert(SS % WAVES == 0, "XCH: whole workgroups per tile");
-            static_assert(SS == WAVES, "XCH: one four-wavefront workgroup per run group");
-            const unsigned gsh = (unsigned)a.split_groups - 1u;  // workgroups per (chunk, tile) item = split_groups = 1 << gsh (1 or 2)
-            const unsigned n_t8 = ((n_tiles + 7u) & ~7u) << gsh; // tiles padded to whole groups of 8 (the surplus ones exit), x groups
+            static_assert(SS % WAVES == 0, "XCH: whole workgroups per tile");
+            constexpr unsigned kH = SS / WAVES;
+            const unsigned n_t8 = (n_tiles + 7u) & ~7u;         // tiles padded to whole groups of 8 (the surplus ones exit)
             const unsigned c = b - unsplit_blocks;
-            const unsigned row = c / n_t8;
-            const unsigned r = c - row * n_t8;
+            const unsigned row = c / (n_t8 * kH);
+            const unsigned r = c - row * (n_t8 * kH);
             const unsigned j = r >> 3;
-            const unsigned tile = (j >> gsh) * 8u + (r & 7u);
+            const unsigned tile = (j / kH) * 8u + (r & 7u);
             if (tile >= n_tiles) return;
-            sp = (int)((j & gsh) * WAVES) + wave;
+            sp = (int)((j % kH) * WAVES) + wave;
             bx = tile;
             chunk = (int64_t)a.split_from + row;
             ktg = 1;
@@ -929,12 +924,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
         s = part_lo;
         part_end = part_hi;
     } else if constexpr (SS > 1) {
-        // (XCH: an item has SS * split_groups wavefronts, one run each - a longer chunk is left to wavefront 0; the wavefronts
-        // of a second group have nothing to do for a chunk of <= SS runs and leave without drawing a ticket)
-        exchange = row_split && (s_end - s_begin) <= (int64_t)(XCH ? SS * a.split_groups : SS) * run_len;
-        if constexpr (XCH) {
-            if (exchange && sp >= SS && (s_end - s_begin) <= (int64_t)SS * run_len) return;
-        }
+        exchange = row_split && (s_end - s_begin) <= (int64_t)SS * run_len;
         if (exchange) {
             s = s_begin + (int64_t)sp * run_len;
             part_end = (s + run_len < s_end) ? s + run_len : s_end;
@@ -983,12 +973,11 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
             if (!exchange) {
                 if (sp != 0) return;                                // a long chunk: part 0 has run all of it
             } else {
-                // publish this wavefront's run term (run sp of the chunk, sp = 0 .. SS * split_groups - 1; a wavefront whose run lies
-                // behind the chunk's end publishes zeros): write-through stores (512 contiguous bytes per instruction), then the ticket
-                constexpr int64_t kItemDoubles = xch_item_bytes(kXchSlots, KT, NC) / 8, kItemWords = xch_item_bytes(kXchSlots, KT, NC) / 4;
+                // publish this run's term (a wavefront whose run lies behind the chunk's end publishes zeros): write-through stores
+                // (512 contiguous bytes per instruction), then the ticket
+                constexpr int64_t kItemDoubles = xch_item_bytes(SS, KT, NC) / 8, kItemWords = xch_item_bytes(SS, KT, NC) / 4;
                 xch_item = DNP_BND(xch_item, n_xch_items, kBndXch);
                 unsigned int* ticket = a.xch_ticket + xch_item * kItemWords;
-                const int n_runs = (int)((s_end - s_begin + run_len - 1) / run_len);      // wave-uniform, 0 .. kXchSlots
                 double* slot = a.xch_terms + xch_item * kItemDoubles + (sp * (KT * NC)) * 64 + (tid & 63);
 #pragma unroll
                 for (int k = 0; k < KT; ++k)
@@ -1010,10 +999,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
                 if ((tid & 63) == 0)
                     drawn = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 drawn = (unsigned)__builtin_amdgcn_readfirstlane((int)drawn);
-                // arrivals of this item: SS wavefronts for a chunk of <= SS runs (a second group's wavefronts have left above), 2 SS
-                // otherwise - from n_runs, not from a.split_groups (held in an SGPR down to here that argument took the kernel from
-                // 78 to 82 SGPRs, and above 80 a CU admits seven 256-thread workgroups instead of eight)
-                if (drawn != (unsigned)((n_runs > SS ? 2 * SS : SS) - 1)) return;   // somebody else arrives last and finishes the item
+                if (drawn != SS - 1) return;                        // somebody else arrives last and finishes the item
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if ((tid & 63) == 0)                                // re-armed for the next launch on this buffer
@@ -1024,29 +1010,14 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
                     // one target's SS * NC loads in flight at a time: all KT * SS * NC at once (what hipcc schedules by itself)
                     // cost 66 VGPRs, i.e. one wavefront per SIMD for the WHOLE kernel
                     if (k > 0) __builtin_amdgcn_sched_barrier(0);
-                    double sum[NC];
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {                   // run order: ((t0 + t1) + t2) + t3, the unsplit form's additions
-                        sum[c] = __hip_atomic_load(terms + (k * NC + c) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        double sum = __hip_atomic_load(terms + (k * NC + c) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                        for (int q = 1; q < SS; ++q) {
-                            // (slots of runs the chunk does not have hold the zero their wavefront published: x + 0 = x)
-                            sum[c] += __hip_atomic_load(terms + ((q * KT + k) * NC + c) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
+                        for (int q = 1; q < SS; ++q)
+                            sum += __hip_atomic_load(terms + ((q * KT + k) * NC + c) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        acc[k][c] = sum;
                     }
-                    if (n_runs > SS) {                               // the second half of the slots, only for chunks that have them:
-#pragma unroll
-                        for (int c = 0; c < NC; ++c) {               // one component's four loads in flight at a time (VGPR budget)
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int q = SS; q < kXchSlots; ++q) {
-                                const double v = __hip_atomic_load(terms + ((q * KT + k) * NC + c) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                sum[c] += (q < n_runs) ? v : 0.0;      // a slot nobody wrote in this launch may hold an older launch's term
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) acc[k][c] = sum[c];
                 }
             }
         }

@@ -568,9 +568,9 @@ def _patch_boxes(work: torch.Tensor, off, idx) -> torch.Tensor:
     return boxes
 
 
-# exchange buffers up to this size stay cached per (thread, device, stream); a larger one (24 704 bytes per split patch and
-# 128-row tile: 58 MB for 3 split patches at 100 000 points, 580 MB at a million) is allocated zeroed for the call and freed
-EXCHANGE_CACHE_MAX_BYTES = 256 << 20
+# exchange buffers up to this size stay cached per (thread, device, stream); a larger one (12 416 bytes per split patch and
+# 128-row tile: 29 MB for 3 split patches at 100 000 points, 780 MB for 8 at a million) is allocated zeroed for the call and freed
+EXCHANGE_CACHE_MAX_BYTES = 256 << 20      # (12 416 bytes per split patch and 128-row tile)
 
 
 def _exchange(nbytes: int, dev: torch.device) -> torch.Tensor:
@@ -597,13 +597,12 @@ def _exchange_drop(dev: torch.device) -> None:
 
 
 def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, eps: float, boxes=None, tile_boxes=None,
-                 w_part: Optional[torch.Tensor] = None, source_split: int = 1, split_groups: int = 1) -> torch.Tensor:
+                 w_part: Optional[torch.Tensor] = None, source_split: int = 1) -> torch.Tensor:
     """dE[p1 - p0, N, 3]: the fields of patches p0..p1 on every point (dnp_patch_fields_tiled_f32).  boxes / tile_boxes:
     the per-cloud box tables of the far-field test (_patch_boxes, _tile_boxes); w_part: receives the per-tile
     interaction partials [p1 - p0, n_tiles, 2 or 3] (see _TileTables; the last dimension = the group slots per tile).
     source_split = -k: the last k patches of the launch as split items whose run
-    terms travel through the exchange buffer (needs both box tables; without them the launch is the plain one), split_groups = 1 / 2:
-    four / eight wavefronts per split item (split patches of <= 512 / <= 1024 points)."""
+    terms travel through the exchange buffer (needs both box tables; without them the launch is the plain one)."""
     lib = _lib.require_device()
     N = work.shape[0]
     dE = torch.empty((p1 - p0, N, 3), dtype=work.dtype, device=work.device)
@@ -624,7 +623,7 @@ def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, ep
         rc = lib.dnp_patch_fields_tiled_f32(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
                                             off.shape[0] - 1, _lib.ptr(point_patch), _lib.ptr(boxes), _lib.ptr(tile_boxes),
                                             p0, p1, float(eps), _lib.ptr(dE), _lib.ptr(w_part),
-                                            2 if w_part is None else int(w_part.shape[-1]), int(source_split), int(split_groups),
+                                            2 if w_part is None else int(w_part.shape[-1]), int(source_split),
                                             _lib.ptr(xch), xch_bytes, _lib.current_stream())
     if rc != 0 and xch is not None:
         _exchange_drop(work.device)               # its counters may not be re-armed: never reuse it
@@ -694,28 +693,34 @@ class _TileTables:
 # -1 % at 32 patches and cost +3 % at 256.  Results do not depend on the choice (bit-identical slabs and partials).
 TAIL_BELOW_PAIRS = 8e9
 TAIL_PATCHES = 3
-# round 5: the tail is sized by its SOURCES, not by a patch count - the last k patches of the launch with at least TAIL_SOURCES
-# points between them (3 of the bench's ~390-point patches; 2..8 of a reference-grid partition's 100..677-point ones), at
-# most TAIL_MAX_PATCHES, and split patches may have up to 1024 points (split_groups = 2: eight wavefronts per item)
+# Round 5: the tail is sized by its SOURCES, not by a patch count and not only for launches whose every patch has 129..512 points
+# (round 4's rule, which never fired on the reference's own grid partitions: patches of 100..677 points): the last k patches of
+# the launch with at least TAIL_SOURCES points between them - 3 of the bench's ~390-point patches, 2..8 of a grid partition's -,
+# at most TAIL_MAX_PATCHES.  A tail patch of <= 128 points is one run (its items are short as they are), one of more than 512
+# points stays with one wavefront per tile (an eight-wavefront item for those was built and measured: slower, see
+# profiles/r05_xch_eight_wavefronts.patch).  One rank's share of eight (tools/gpu_rank_share.py, profiles/r05_rank_share_partitions.txt):
+# bench partition 0.930 (plain launch 0.903), the reference's grid partition of the same sphere 0.910 (0.876), boxunion's 369
+# patches of config 3 0.925 (0.839).
 TAIL_SOURCES = 1000
 TAIL_MAX_PATCHES = 8
 
 
-def _pick_source_split(sizes_block: np.ndarray, n_targets: int):
-    """(source_split, split_groups) for a launch over patches of these sizes: (1, 1), or (-k, g) - the last k patches split,
-    g four-wavefront workgroups per split item - when the launch is below TAIL_BELOW_PAIRS.  k = the fewest trailing patches
-    holding TAIL_SOURCES points (TAIL_PATCHES for patches of the bench's size), g = 2 when one of them has more than 512
-    points; no tail when one has more than 1024 (it would be left to a single wavefront) or the launch is too small to have k."""
+def _pick_source_split(sizes_block: np.ndarray, n_targets: int) -> int:
+    """source_split for a launch over patches of these sizes: 1, or -k (the last k patches split) when the launch is below
+    TAIL_BELOW_PAIRS: k = the fewest trailing patches whose members of <= 512 points (the ones whose items become short) hold
+    TAIL_SOURCES points (TAIL_PATCHES for patches of the bench's size), at most TAIL_MAX_PATCHES; no tail when none of them
+    has 129..512 points (nothing would be split)."""
     n = len(sizes_block)
     if n == 0 or float(sizes_block.sum()) * float(n_targets) >= TAIL_BELOW_PAIRS:
-        return 1, 1
-    csum = np.cumsum(np.asarray(sizes_block, dtype=np.int64)[::-1])
+        return 1
+    rev = np.asarray(sizes_block, dtype=np.int64)[::-1]
+    csum = np.cumsum(np.where(rev <= 512, rev, 0))
     k = int(np.searchsorted(csum, TAIL_SOURCES, side="left")) + 1
     k = min(k, TAIL_MAX_PATCHES, n)
-    biggest = int(np.asarray(sizes_block)[n - k:].max())
-    if biggest > 1024 or biggest <= 128:
-        return 1, 1
-    return -k, (2 if biggest > 512 else 1)
+    tail = rev[:k]
+    if not bool(np.any((tail > 128) & (tail <= 512))):
+        return 1
+    return -k
 
 
 def _slabs_and_rows(swork, off, point_patch, b0: int, b1: int, eps: float, boxes, tiles: "_TileTables", sizes=None):
@@ -724,19 +729,18 @@ def _slabs_and_rows(swork, off, point_patch, b0: int, b1: int, eps: float, boxes
     the K3 pass over the slabs."""
     P = off.shape[0] - 1
     f64 = swork.dtype == torch.float64
-    split, groups = (1, 1) if (sizes is None or tiles is None or boxes is None or f64) else \
-        _pick_source_split(np.asarray(sizes)[b0:b1], swork.shape[0])
+    split = 1 if (sizes is None or tiles is None or boxes is None or f64) else _pick_source_split(np.asarray(sizes)[b0:b1], swork.shape[0])
     if tiles is not None and tiles.fused and ((boxes is not None and eps >= 1e-30) or (f64 and eps > 0)):
         lib = _lib.require_device()
         K, N = b1 - b0, swork.shape[0]
         w_part = torch.empty((K, tiles.n_tiles, tiles.slots), dtype=torch.float64, device=swork.device)
-        dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, tiles.boxes, w_part, split, groups)
+        dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, tiles.boxes, w_part, split)
         W = torch.empty((K, P), dtype=torch.float64, device=swork.device)            # (tile geometry and sums: the same in both precisions)
         with _on_device(swork.device):
             _lib.check(lib.dnp_interactions_from_tiles(_lib.ptr(w_part), tiles.slots, K, N, _lib.ptr(point_patch), _lib.ptr(off), P,
                                                        _lib.ptr(W), _lib.current_stream()))
         return dE, W
-    dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, None if tiles is None else tiles.boxes, None, split, groups)
+    dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, None if tiles is None else tiles.boxes, None, split)
     return dE, _interaction_rows(dE, swork, off, None)
 
 

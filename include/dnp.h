@@ -180,14 +180,14 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts,
  * tile.  No LDS and no barrier: the other patches of the launch run exactly as in the plain form, the launch's last
  * resident set consists of items a third as long and the chip drains in a third of the time.  The drivers use k = 3 for
  * launches below 8 10^9 pairs (profiles/r04_xch_ab.txt: -11 % at 16 of the bench's patches, -3.7 % at 32, -0.5 % at 128).
- * split_groups (1 or 2; round 5): four-wavefront workgroups per split (patch, tile) item.  1: wavefronts 0..3 on the runs 0..3 -
- * for split patches of <= 512 points; 2: a second workgroup takes the runs 4..7 (<= 1024 points; the last of EIGHT arrivers
- * finishes the item), so the reference's grid partitions (patches of 100..677 points) get the tail too.  A split patch longer
- * than 512 * split_groups points is evaluated by one wavefront per tile, patches of <= 128 points are a single run.
- * dE and w_part do not depend on source_split or split_groups (the same fp32 runs, the same fp64 additions in run order);
- * without both tables a launch with source_split < 0 is the plain one.
- * exchange: device scratch of at least dnp_patch_exchange_bytes(N, k) bytes = k * ceil(N / 128) * 24 704 (a 128-byte counter
- * line + 8 run slots x 6 doubles x 64 lanes per split (patch, tile) item; NULL / 0 with source_split = 1).  CONTRACT: the
+ * dE and w_part do not depend on source_split (the same fp32 runs, the same fp64 additions in run order); a split patch of
+ * more than 512 points is evaluated by one wavefront per tile whatever source_split says, patches of <= 128 points are a
+ * single run - the drivers therefore size the tail by its sources, not by a patch count (field_utils._pick_source_split:
+ * the fewest trailing patches holding 1000 points, 2..8 of them); without both tables a launch with source_split < 0 is the
+ * plain one.  (An eight-wavefront item for patches of 513..1024 points was built and measured in round 5 and not kept:
+ * profiles/r05_xch_eight_wavefronts.patch.)
+ * exchange: device scratch of at least dnp_patch_exchange_bytes(N, k) bytes = k * ceil(N / 128) * 12 416 (a 128-byte counter
+ * line + 4 run slots x 6 doubles x 64 lanes per split (patch, tile) item; NULL / 0 with source_split = 1).  CONTRACT: the
  * buffer is zero before its first use (dnp_exchange_init, or any memset); every launch leaves its arrival counters zero
  * again, and a record's place in the buffer depends on its (patch, tile) index only, so one buffer serves launches of any
  * size one after the other - on ONE stream at a time.  A launch with source_split < 0 and no (or too small a) buffer
@@ -200,7 +200,7 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts,
                                const int64_t* patch_off, const int64_t* patch_idx, int64_t P,
                                const int64_t* point_patch, const float* patch_box, const float* tile_box,
                                int64_t p_begin, int64_t p_end, float eps,
-                               float* dE, double* w_part, int w_slots, int source_split, int split_groups,
+                               float* dE, double* w_part, int w_slots, int source_split,
                                void* exchange, size_t exchange_bytes, void* stream);
 /* The same slabs for a FLOAT64 cloud (round 5).  The reference computes in the dtype it is handed (field_utils.py:96-109; its
  * socket path hands it float64, util.py:71-77), so on a float64 cloud the greedy drivers' per-patch fields (field_utils.py:

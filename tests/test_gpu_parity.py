@@ -472,8 +472,8 @@ def test_source_split_does_not_change_a_bit(dev):
     assert sizes.min() > 128 and sizes.max() <= 512
     point_patch = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
     boxes, tiles = fu._patch_boxes(swork, off, None), fu._TileTables(swork, sizes)
-    assert fu._pick_source_split(sizes[:16], N) == (-3, 1) and fu._pick_source_split(sizes[:32], N) == (-3, 1)
-    assert fu._pick_source_split(sizes[:128], N) == (-3, 1) and fu._pick_source_split(sizes, N) == (1, 1)
+    assert fu._pick_source_split(sizes[:16], N) == -3 and fu._pick_source_split(sizes[:32], N) == -3
+    assert fu._pick_source_split(sizes[:128], N) == -3 and fu._pick_source_split(sizes, N) == 1
     res = {}
 
     def poison(shape):       # _patch_slabs returns torch.empty memory: make sure a launch that wrote nothing cannot pass on stale rows
@@ -498,13 +498,13 @@ def test_source_split_does_not_change_a_bit(dev):
     for k in (5, 2):
         dEr = torch.full((24, N, 3), float("nan"), dtype=torch.float32, device=dev)
         rc = lib.dnp_patch_fields_tiled_f32(_lib.ptr(swork), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch), _lib.ptr(boxes),
-                                            _lib.ptr(tiles.boxes), 40, 64, 1e-5, _lib.ptr(dEr), None, 2, -k, 1, _lib.ptr(own), nb,
+                                            _lib.ptr(tiles.boxes), 40, 64, 1e-5, _lib.ptr(dEr), None, 2, -k, _lib.ptr(own), nb,
                                             _lib.current_stream())
         assert rc == 0 and torch.equal(dEr, res[1][0]), k
     # a split launch without the buffer is refused, not run wrong
     dE = torch.empty((24, N, 3), dtype=torch.float32, device=dev)
     rc = _lib.load().dnp_patch_fields_tiled_f32(_lib.ptr(swork), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch), _lib.ptr(boxes),
-                                                _lib.ptr(tiles.boxes), 40, 64, 1e-5, _lib.ptr(dE), None, 2, -3, 1, None, 0,
+                                                _lib.ptr(tiles.boxes), 40, 64, 1e-5, _lib.ptr(dE), None, 2, -3, None, 0,
                                                 _lib.current_stream())
     assert rc == -3 and b"exchange buffer" in _lib.load().dnp_last_error()
     k = 51
@@ -523,18 +523,27 @@ def test_source_split_does_not_change_a_bit(dev):
     boxes2, tiles2 = fu._patch_boxes(sw2, off2, None), fu._TileTables(sw2, sizes2)
     a = fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, None, 1)
     for tail in (-1, -2, -4, -9, -10, -50, -3):
-        for groups in (1, 2):         # 2 (round 5): eight wavefronts per split item - the 513- and 900-point patches are split too
-            poison(tuple(a.shape))
-            b = fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, None, tail, groups)
-            assert torch.equal(a, b), (tail, groups)
-    # ... with the interaction partials, two and three group slots (the 64- / 41-point patches put three groups into a tile)
-    assert tiles2.slots == 3
-    wa = torch.full((len(sizes2), tiles2.n_tiles, 3), float("nan"), dtype=torch.float64, device=dev)
-    fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, wa, 1)
-    for tail, groups in ((-4, 2), (-50, 2), (-3, 1)):
+        poison(tuple(a.shape))
+        b = fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, None, tail)
+        assert torch.equal(a, b), tail
+    # ... with the interaction partials in their three-slot form (round 5): a cut whose 50- / 30-point patches put three groups
+    # into one 128-row tile - slabs and partials of the split launches equal the plain launch's, W from them equals K3's
+    sizes3 = np.array([200, 50, 30, 300, 512, 513, 100, 100, 390], dtype=np.int64)
+    off3 = t(np.concatenate([[0], np.cumsum(sizes3)])).to(dev)
+    n3 = int(sizes3.sum())
+    sw3 = swork[:n3].contiguous()
+    pp3 = torch.repeat_interleave(torch.arange(len(sizes3), device=dev), off3[1:] - off3[:-1])
+    boxes3, tiles3 = fu._patch_boxes(sw3, off3, None), fu._TileTables(sw3, sizes3)
+    assert tiles3.slots == 3
+    wa = torch.full((len(sizes3), tiles3.n_tiles, 3), float("nan"), dtype=torch.float64, device=dev)
+    a3 = fu._patch_slabs(sw3, off3, None, pp3, 0, len(sizes3), 1e-5, boxes3, tiles3.boxes, wa, 1)
+    for tail in (-4, -50, -3):
         wb = torch.full_like(wa, float("nan"))
-        b = fu._patch_slabs(sw2, off2, None, pp2, 0, len(sizes2), 1e-5, boxes2, tiles2.boxes, wb, tail, groups)
-        assert torch.equal(a, b) and torch.equal(wa, wb), (tail, groups)
+        b3 = fu._patch_slabs(sw3, off3, None, pp3, 0, len(sizes3), 1e-5, boxes3, tiles3.boxes, wb, tail)
+        assert torch.equal(a3, b3) and torch.equal(wa, wb), tail
+    W3 = fu._interaction_rows(a3, sw3, off3, None)
+    _, Wt = fu._slabs_and_rows(sw3, off3, pp3, 0, len(sizes3), 1e-5, boxes3, tiles3, sizes3)
+    assert float((Wt - W3).abs().max()) <= 1e-12 * float(W3.abs().max())
     for k in (1, 2, 5, 9):
         lo, hi = int(off2[k]), int(off2[k + 1])
         others = (pp2 != k).cpu()

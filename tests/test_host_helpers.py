@@ -248,18 +248,18 @@ def test_fused_interaction_rule_and_source_split_policy():
         worst = max(len(np.unique(grp[i:i + 128])) for i in range(0, n, 128))
         assert fu._tile_group_slots(sizes, n, 128) == (2 if worst <= 2 else 3 if worst == 3 else 0)
     big = np.full(256, 390)
-    assert fu._pick_source_split(big, 100000) == (1, 1) and fu._pick_source_split(big[:16], 100000) == (-3, 1)
-    assert fu._pick_source_split(big[:32], 100000) == (-3, 1)             # a rank's share of 8: 1.25e9 pairs
-    assert fu._pick_source_split(big[:128], 100000) == (-3, 1)            # a rank's share of 2: 5e9 pairs, still below the threshold
-    assert fu._pick_source_split(big[:210], 100000) == (1, 1)             # 8.2e9 pairs: above it
-    # the tail is sized by its sources (round 5): the fewest trailing patches holding 1000 points, eight wavefronts per item
-    # when one of them has more than 512 points, no tail when one has more than 1024 or the biggest is a single run
-    assert fu._pick_source_split(np.array([128, 300]), 1000) == (-2, 1) and fu._pick_source_split(np.array([129, 512]), 1000) == (-2, 1)
-    assert fu._pick_source_split(np.array([300, 600]), 1000) == (-2, 2) and fu._pick_source_split(np.array([400, 677, 677]), 1000) == (-2, 2)
-    assert fu._pick_source_split(np.array([500, 100, 100, 100, 400, 100, 100, 100, 100, 100]), 1000) == (-7, 1)
-    assert fu._pick_source_split(np.full(20, 100), 1000) == (1, 1)         # single-run patches only: nothing to split
-    assert fu._pick_source_split(np.array([300, 1025]), 1000) == (1, 1)
-    assert fu._pick_source_split(np.array([], dtype=np.int64), 1000) == (1, 1)
+    assert fu._pick_source_split(big, 100000) == 1 and fu._pick_source_split(big[:16], 100000) == -3
+    assert fu._pick_source_split(big[:32], 100000) == -3                  # a rank's share of 8: 1.25e9 pairs
+    assert fu._pick_source_split(big[:128], 100000) == -3                 # a rank's share of 2: 5e9 pairs, still below the threshold
+    assert fu._pick_source_split(big[:210], 100000) == 1                  # 8.2e9 pairs: above it
+    # the tail is sized by its sources (round 5): the fewest trailing patches holding 1000 points, at most 8; a patch of more
+    # than 512 points in it stays with one wavefront per tile; no tail when every tail patch is a single run
+    assert fu._pick_source_split(np.array([128, 300]), 1000) == -2 and fu._pick_source_split(np.array([129, 512]), 1000) == -2
+    assert fu._pick_source_split(np.array([300, 600]), 1000) == -2 and fu._pick_source_split(np.array([400, 677, 677]), 1000) == -3
+    assert fu._pick_source_split(np.array([500, 100, 100, 100, 400, 100, 100, 100, 100, 100]), 1000) == -7
+    assert fu._pick_source_split(np.full(20, 100), 1000) == 1              # single-run patches only: nothing to split
+    assert fu._pick_source_split(np.array([300, 1025]), 1000) == -2 and fu._pick_source_split(np.array([100, 1025]), 1000) == 1
+    assert fu._pick_source_split(np.array([], dtype=np.int64), 1000) == 1
 
 
 def test_store_normals_writes_any_host_tensor_through_one_copy():

@@ -87,7 +87,7 @@ def main():
             rc = libs[name].dnp_patch_fields_tiled_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch),
                                                        _lib.ptr(boxes), _lib.ptr(tile_boxes), 0, P, 1e-5,
                                                        _lib.ptr(dE[name]), _lib.ptr(w_part) if name != "tiled" else None,
-                                                       2, 1, 1, None, 0, stream)
+                                                       2, 1, None, 0, stream)
         else:
             rc = libs[name].dnp_patch_fields_boxed_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch),
                                                        _lib.ptr(boxes), 0, P, 1e-5, _lib.ptr(dE[name]), stream)

@@ -107,8 +107,6 @@ def run(budget=180.0, seed=0):
                             "all split": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, None, allp),
                             "all split + partials": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, wp[allp], allp),
                             f"split {tail}": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, None, tail),
-                            f"split {tail} x 8 wavefronts": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, None, tail, 2),
-                            "all split x 8 wavefronts": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, None, allp, 2),
                             f"split {tail} + partials": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps, boxes, tiles.boxes, wp[tail], tail),
                             "no boxes": fu._patch_slabs(sw, off, None, pp, 0, n_p, eps)}
                 for name, v in variants.items():

@@ -50,26 +50,21 @@ def run(name, cloud, patches):
         b = fu._balanced_blocks(sizes, world)
         lo, hi = int(b[0]), int(b[1])
         pairs = float(sizes[lo:hi].sum()) * N
-        split, groups = fu._pick_source_split(sizes[lo:hi], N)
+        split = fu._pick_source_split(sizes[lo:hi], N)
         wp = torch.empty((hi - lo, tiles.n_tiles, tiles.slots), dtype=torch.float64, device=dev) if tiles.fused else None
-        ref = fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, 1, 1)
-        got = fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, split, groups)
+        ref = fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, 1)
+        got = fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, split)
         same = bool(torch.equal(ref, got))
         del ref, got
-        t_tail, _ = timed(lambda: fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, split, groups))
-        t_plain, _ = timed(lambda: fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, 1, 1))
+        t_tail, _ = timed(lambda: fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, split))
+        t_plain, _ = timed(lambda: fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, 1))
         if world == 1:
             full = (min(t_tail, t_plain), pairs)
         ideal = full[0] * pairs / full[1]
-        # the alternatives the policy did not choose: the same tail length with four / eight wavefronts per item
-        k = -split if split < 0 else min(3, hi - lo)
-        alt = []
-        for g in (1, 2):
-            t_alt, _ = timed(lambda: fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, -k, g))
-            alt.append(f"-{k}x{g}: {t_alt:7.4f}")
-        print(f"N={world}: rank 0 = patches [{lo},{hi}) {pairs:.3e} pairs, source_split {split} x {groups} group(s): "
+        k = -split if split < 0 else 0
+        print(f"N={world}: rank 0 = patches [{lo},{hi}) {pairs:.3e} pairs, source_split {split}: "
               f"{t_tail:7.4f} ms (share of ideal {ideal / t_tail:5.3f}) | plain launch {t_plain:7.4f} ms ({ideal / t_plain:5.3f}) | "
-              f"forced {', '.join(alt)} | tail patch sizes {sizes[hi - k:hi].tolist()} | slabs bit-identical: {same}", flush=True)
+              f"tail patch sizes {sizes[hi - k:hi].tolist() if k else []} | slabs bit-identical: {same}", flush=True)
 
 
 pc, patches, _ = headline_workload()

@@ -158,7 +158,7 @@ def main():
             a.record()
             rc = lib.dnp_patch_fields_tiled_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(point_patch),
                                                 _lib.ptr(boxes), _lib.ptr(tile_boxes), 0, K, 1e-5, _lib.ptr(dE),
-                                                _lib.ptr(w_part), 2, ss, 1, None, 0, stream)
+                                                _lib.ptr(w_part), 2, ss, None, 0, stream)
             b.record()
             assert rc == 0
             torch.cuda.synchronize()

@@ -34,7 +34,7 @@ main = torch.cuda.current_stream()
 
 def launch(K, ss, exchange):
     rc = lib.dnp_patch_fields_tiled_f32(_lib.ptr(pts), N, 6, _lib.ptr(off), None, P, _lib.ptr(pp), _lib.ptr(boxes),
-                                        _lib.ptr(tiles.boxes), 0, K, 1e-5, _lib.ptr(dE), _lib.ptr(wp), 2, ss, 1,
+                                        _lib.ptr(tiles.boxes), 0, K, 1e-5, _lib.ptr(dE), _lib.ptr(wp), 2, ss,
                                         _lib.ptr(xch) if exchange else None, xch.numel() if exchange else 0,
                                         ctypes.c_void_p(main.cuda_stream))
     assert rc == 0, lib.dnp_last_error()
