@@ -36,10 +36,21 @@ constexpr int kKTScalar = 2, kKTLds = 4;
 #ifndef DNP_KT_TILES      // A/B builds (tools/gpu_k1_ab.py K1_SHAPES)
 #define DNP_KT_TILES 8
 #endif
-// ... used once that still leaves >= 8 target tiles (T >= 4096 / 8192).  Round 5: 16 -> 8 - the representatives driver's final
-// field (93 411 sources x 6589 targets) 393 -> 375 us, 100 000 x 4096 and 30 000 x 7000 level; 4 costs the latter 20 %
-// (profiles/r05_kt_tiles_ab.txt)
+// ... used once that still leaves >= 8 target tiles of the scalar kernel (T >= 4096) / 16 of the LDS kernel (T >= 16 384).
+// Round 5: 16 -> 8 for the scalar kernel - the representatives driver's final field (93 411 sources x 6589 targets) 393 -> 375 us,
+// 100 000 x 4096 and 30 000 x 7000 level; 4 costs the latter 20 % (profiles/r05_kt_tiles_ab.txt)
 constexpr int64_t kTilesForLarge = DNP_KT_TILES;
+#ifndef DNP_LDS_KT_TILES
+#define DNP_LDS_KT_TILES 16
+#endif
+constexpr int64_t kTilesForLargeLds = DNP_LDS_KT_TILES;
+// workgroups an LDS-kernel launch aims at (small problems).  8192 = round 1's rule
+#ifndef DNP_LDS_WANT_BLOCKS
+#define DNP_LDS_WANT_BLOCKS 8192
+#endif
+#ifndef DNP_LDS_TAPER      // tapered chunk lengths in LDS-kernel launches too (0: equal chunks)
+#define DNP_LDS_TAPER 1
+#endif
 constexpr size_t kSlabCap = (size_t)1 << 30;  // bytes of partial slab per round
 struct Plan {
     // one entry per round; every round is a run of whole leaves
@@ -93,7 +104,8 @@ static int64_t choose_chunks(int64_t S, int64_t T, int64_t t_tiles, int64_t n_le
         return want < n_leaves ? n_leaves : want;
     }
     if (!scalar_kernel) {        // LDS kernel (small problems, gathered sources): ~8192 workgroups, the round-1 rule
-        const int64_t want = ceil_div((int64_t)8192, t_tiles);
+        const int64_t want = DNP_LDS_WANT_BLOCKS >= 8192 ? ceil_div((int64_t)DNP_LDS_WANT_BLOCKS, t_tiles)
+                                                         : (DNP_LDS_WANT_BLOCKS / t_tiles > 0 ? DNP_LDS_WANT_BLOCKS / t_tiles : 1);
         return want < n_leaves ? n_leaves : want;
     }
     int64_t want = S / kChunkSources;
@@ -113,7 +125,7 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
     if (S > 0) split_leaves(0, S, max_pts, cuts);
     // small problems are latency bound: prefer many short workgroups (1 target per lane, chunks down to 64
     // sources); large ones amortise the source fetch over 2 (scalar kernel) / 4 (LDS kernel) targets per lane
-    plan.kt = (T >= (int64_t)kBlock * kKTLarge * kTilesForLarge) ? kKTLarge : 1;
+    plan.kt = (T >= (int64_t)kBlock * kKTLarge * (scalar_kernel ? kTilesForLarge : kTilesForLargeLds)) ? kKTLarge : 1;
 #ifdef DNP_FORCE_KT       // planning experiments only
     plan.kt = DNP_FORCE_KT;
 #endif
@@ -167,9 +179,9 @@ static Plan make_plan(int64_t S, int64_t T, int64_t max_pts, int nc, size_t elem
 #ifndef DNP_TAPER_MIN
 #define DNP_TAPER_MIN 0.25
 #endif
-    auto taper_weight = [](int64_t i, int64_t m) -> double {      // relative length of chunk i of m
+    auto taper_weight = [scalar_kernel](int64_t i, int64_t m) -> double {      // relative length of chunk i of m
         const double knee = DNP_TAPER_KNEE * (double)m;
-        if (!DNP_TAPER || m < 8 || (double)i < knee) return 1.0;
+        if (!DNP_TAPER || (!scalar_kernel && !DNP_LDS_TAPER) || m < 8 || (double)i < knee) return 1.0;
         return 1.0 - (1.0 - DNP_TAPER_MIN) * ((double)i - knee) / ((double)m - knee);
     };
     Plan::Round cur;

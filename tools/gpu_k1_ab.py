@@ -35,6 +35,7 @@ def main():
         libs[name] = bind(path if os.path.isabs(path) else os.path.join(ROOT, path))
     dev = torch.device("cuda:0")
     clouds = {"fandisk": torch.from_numpy(load_golden("G5_fandisk_allpairs")["pc"]).to(dev), "sphere3k": sphere(3000).to(dev),
+              "sphere8k": sphere(8000).to(dev), "sphere16k": sphere(16000).to(dev), "sphere22k": sphere(22000).to(dev),
               "sphere30k": sphere(30000).to(dev), "sphere100k": sphere(100000).to(dev)}
     from tools.workloads import headline_workload
     from dipole_normal_prop_amd import util
@@ -88,9 +89,23 @@ def main():
                 a.record(); launch(name); b.record()
                 torch.cuda.synchronize()
                 times[name].append(a.elapsed_time(b))
+        # the same calls back to back (what bench.py's legs time): 30 launches between two events, three rounds, best round
+        b2b = {}
+        for name in libs:
+            best = 1e9
+            for _ in range(3):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(30):
+                    launch(name)
+                b.record()
+                torch.cuda.synchronize()
+                best = min(best, a.elapsed_time(b) / 30)
+            b2b[name] = best * 1e3
         for name, ts in times.items():
             ts = np.array(ts) * 1e3
-            print(f"{cname:11s} {name:12s} median {np.median(ts):9.1f} us  min {ts.min():9.1f}  ({n * n / np.median(ts) / 1e3:7.1f} Gpairs/s)", flush=True)
+            print(f"{cname:11s} {name:12s} median {np.median(ts):9.1f} us  min {ts.min():9.1f}  ({n * n / np.median(ts) / 1e3:7.1f} Gpairs/s)  "
+                  f"back to back {b2b[name]:9.1f} us", flush=True)
 
 
 if __name__ == "__main__":
