@@ -186,7 +186,7 @@ def other_configs(dev, fu, util, pts_sorted, patch_ranges):
         i64 = lambda a: torch.from_numpy(a.astype(np.int64)).to(dev)
         reps = util.RepLists(util.PatchList(i64(g15["rep_idx"]), np.diff(g15["rep_off"]), disjoint=True),
                              util.PatchList(i64(g15["rest_idx"]), np.diff(g15["rest_off"]), disjoint=True))
-        t = timed(lambda: fu.strongest_field_propagation_reps(cloud.clone(), reps, diffuse=True), 3)
+        t = timed(lambda: fu.strongest_field_propagation_reps(cloud.clone(), reps, diffuse=True), 10)
         nrep = int(g15["rep_off"][-1])
         out["config3_boxunion_reps_propagation"] = {
             "points": int(cloud.shape[0]), "patches": len(reps), "representatives": nrep, "ms": t * 1e3,
@@ -208,14 +208,14 @@ def other_configs(dev, fu, util, pts_sorted, patch_ranges):
                                                    "pairs_per_s": float(N_POINTS) ** 2 / t, "dtype": "f32"}
     # ---- the float64 entry points (round 5; the reference's socket path hands float64 clouds to the same functions): pairs/s
     # and the fraction of the FP64 vector peak at the 33 flop per pair of the fp32 roofline
-    def f64_leg(pairs, t):
-        return {"ms": t * 1e3, "pairs_per_s": pairs / t, "dtype": "f64",
-                "frac_of_fp64_valu_peak": pairs * FLOP_PER_PAIR / t / 1e12 / FP64_VALU_PEAK_TFLOPS}
+    def f64_leg(pairs, t, flop=FLOP_PER_PAIR):
+        return {"ms": t * 1e3, "pairs_per_s": pairs / t, "dtype": "f64", "flop_per_pair": flop,
+                "frac_of_fp64_valu_peak": pairs * flop / t / 1e12 / FP64_VALU_PEAK_TFLOPS}
     grid = util.gen_grid().to(dev)
     t = timed(lambda: fu.potential(pts_sorted, grid), 20)
     out["potential_100k_x_1000_lattice"] = {"ms": t * 1e3, "pairs_per_s": float(N_POINTS) * grid.shape[0] / t, "dtype": "f32"}
     pts64, tgt64, grid64 = pts_sorted.double(), tgt.double(), grid.double()
-    out["potential_100k_x_1000_lattice_f64"] = f64_leg(float(N_POINTS) * grid.shape[0], timed(lambda: fu.potential(pts64, grid64), 20))
+    out["potential_100k_x_1000_lattice_f64"] = f64_leg(float(N_POINTS) * grid.shape[0], timed(lambda: fu.potential(pts64, grid64), 20), 13)
     out["allpairs_100k_field_grad_f64"] = f64_leg(float(N_POINTS) ** 2, timed(lambda: fu.field_grad(pts64, pts64), 3))
     out["config5_reference_field_100k_to_100k_f64"] = f64_leg(float(N_POINTS) ** 2, timed(lambda: fu.reference_field(pts64, tgt64), 3))
     t = timed(lambda: fu.strongest_field_propagation(pts64.clone(), list(enumerate(patch_ranges)), patch_ranges, diffuse=True), 3)

@@ -224,33 +224,44 @@ __global__ __launch_bounds__(kOrderThreads) void xie_order_reg_kernel(const F* _
 }
 
 // ---- the diffuse pass of the ordered propagation (field_utils.py:597-603): out[r][i] = sum_j M[i][j] * w[r][j] for the R final
-// weight vectors at once - one pass over the N x N matrix (HBM-bound: 4 N^2 bytes), one wavefront per matrix row, up to kDotOrders
-// weight vectors per pass (they stay in cache: R N values).  Products rounded in F, sums in fp64 in a fixed order (lane-strided
-// partial sums, then the butterfly), the result rounded to F.  (Rounds 1-4 ran this as a torch matmul - the one rocBLAS call on
-// the path.)
-constexpr int kDotOrders = 8;
+// weight vectors at once - one pass over the N x N matrix (HBM-bound: 4 N^2 bytes), up to kDotOrders weight vectors per pass.
+// A wavefront takes kDotRows consecutive matrix rows: the weights of a column are loaded once and used for all of them (the
+// first form - one row per wavefront - issued one load of the matrix and R loads of weights per element and reached 0.8 TB/s:
+// bound by load issue, not by HBM; profiles/SUMMARY_r05.md).  Products rounded in F, sums in fp64 in a fixed order (per lane its
+// columns lane, lane + 64, ... ascending, then the butterfly over the lanes), the result rounded to F.  (Rounds 1-4 ran this
+// as a torch matmul - the one rocBLAS call on the path.)
+constexpr int kDotOrders = 5;           // the callers' `times` is odd: 1 or 5 visiting orders - one pass over the matrix for up to 5
 template <typename F>
 __global__ __launch_bounds__(256) void xie_rowdots_kernel(const F* __restrict__ M, int64_t N, const F* __restrict__ weights,
                                                           int64_t R, int64_t r0, F* __restrict__ out) {
+    constexpr int kDotRows = sizeof(F) == 4 ? 8 : 4;      // 40 / 20 fp64 sums per lane
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= N) return;
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kDotRows;
+    if (i0 >= N) return;
     const int nr = (int)((R - r0) < kDotOrders ? (R - r0) : kDotOrders);
-    const F* row = M + i * N;
-    double s[kDotOrders];
+    double s[kDotRows][kDotOrders];
 #pragma unroll
-    for (int r = 0; r < kDotOrders; ++r) s[r] = 0.0;
+    for (int q = 0; q < kDotRows; ++q)
+#pragma unroll
+        for (int r = 0; r < kDotOrders; ++r) s[q][r] = 0.0;
     for (int64_t j = lane; j < N; j += 64) {
-        const F m = row[j];
+        F w[kDotOrders], m[kDotRows];
 #pragma unroll
-        for (int r = 0; r < kDotOrders; ++r)
-            if (r < nr) s[r] += (double)(m * weights[(r0 + r) * N + j]);
+        for (int r = 0; r < kDotOrders; ++r) w[r] = weights[(r0 + (r < nr ? r : 0)) * N + j];     // clamped: all loads unconditional
+#pragma unroll
+        for (int q = 0; q < kDotRows; ++q) m[q] = M[(i0 + q < N ? i0 + q : N - 1) * N + j];
+#pragma unroll
+        for (int q = 0; q < kDotRows; ++q)
+#pragma unroll
+            for (int r = 0; r < kDotOrders; ++r) s[q][r] += (double)(m[q] * w[r]);
     }
 #pragma unroll
-    for (int r = 0; r < kDotOrders; ++r) {
-        for (int off = 32; off > 0; off >>= 1) s[r] += __shfl_xor(s[r], off, 64);
-        if (lane == 0 && r < nr) out[(r0 + r) * N + i] = (F)s[r];
-    }
+    for (int q = 0; q < kDotRows; ++q)
+#pragma unroll
+        for (int r = 0; r < kDotOrders; ++r) {
+            for (int off = 32; off > 0; off >>= 1) s[q][r] += __shfl_xor(s[q][r], off, 64);
+            if (lane == 0 && r < nr && i0 + q < N) out[(r0 + r) * N + i0 + q] = (F)s[q][r];
+        }
 }
 
 template <typename F>
@@ -306,7 +317,7 @@ static int run_xie_rowdots(const F* M, int64_t N, const F* weights, int64_t R, F
     if (N == 0 || R == 0) return DNP_OK;
     DNP_REQUIRE(M && weights && out, "NULL pointer");
     for (int64_t r0 = 0; r0 < R; r0 += kDotOrders)
-        hipLaunchKernelGGL(xie_rowdots_kernel<F>, dim3((unsigned)ceil_div(N, (int64_t)4)), dim3(256), 0, stream, M, N, weights, R, r0, out);
+        hipLaunchKernelGGL(xie_rowdots_kernel<F>, dim3((unsigned)ceil_div(N, (int64_t)4 * (sizeof(F) == 4 ? 8 : 4))), dim3(256), 0, stream, M, N, weights, R, r0, out);
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
 }

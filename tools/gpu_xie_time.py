@@ -80,3 +80,25 @@ for n in (4000, 10000, 16000):
             print(f"N={n:6d}   dnp_xie_order_f32 {name}: {mn:8.3f} ms = {mn * 1e3 / n:.2f} us per step")
         (w1, i1), (w2, i2) = res.values()
         print(f"N={n:6d}   weights and interactions bit-identical between the two forms: {bool(torch.equal(w1, w2) and torch.equal(i1, i2))}")
+
+# ---- round 5: the diffuse pass (dnp_xie_rowdots_*, one pass over M for all orders) against the torch matmul it replaced, the
+# kNN mask (brute-force top-k on the device, field_utils._xie_knn_mask) and the float64 forms
+for n in (4000, 10000):
+    gen = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 6, generator=gen)
+    pc = torch.cat([0.4 * x[:, :3] / x[:, :3].norm(dim=1, keepdim=True), torch.nn.functional.normalize(x[:, 3:], dim=1)], 1).to(dev)
+    for dt, name in ((torch.float32, "f32"), (torch.float64, "f64")):
+        pcd = pc.to(dt)
+        M = fu.xie_intersaction(pcd, pcd, 0.1, -1, 3).contiguous()
+        w = torch.where(torch.rand(5, n, device=dev) < 0.5, -1.0, 1.0).to(dt)
+        out = torch.empty_like(w)
+        fn = lib.dnp_xie_rowdots_f64 if dt == torch.float64 else lib.dnp_xie_rowdots_f32
+        med, mn = timed(lambda: fn(_lib.ptr(M), n, _lib.ptr(w), 5, _lib.ptr(out), _lib.current_stream()))
+        medt, mnt = timed(lambda: torch.matmul(w, M.transpose(0, 1)))
+        gb = n * n * M.element_size() / 1e9
+        print(f"N={n:6d} {name} diffuse pass, 5 orders: dnp_xie_rowdots {mn * 1e3:8.1f} us min ({gb / mn * 1e3:6.0f} GB/s of the matrix) | "
+              f"torch w @ M.T (rocBLAS) {mnt * 1e3:8.1f} us")
+    med, mn = timed(lambda: fu._xie_knn_mask(pc, pc, 20), reps=5)
+    print(f"N={n:6d} kNN mask (k = 20, brute-force top-k, fp64 distances): {med:8.2f} ms median / {mn:8.2f} min")
+    med, mn = timed(lambda: fu.xie_propagation_points_in_order(pc.double(), 0.1, [np.arange(n)], diffuse=True), reps=3)
+    print(f"N={n:6d} f64 ordered propagation, 1 order, diffuse: {med:8.2f} ms = {med * 1e3 / n:.2f} us per step (matrix included)")
