@@ -537,7 +537,7 @@ def main():
                      "gather_rows_ms_min": float(t[4]), "pairs": float(t[5])} for r, t in enumerate(allr)]
     # HBM traffic cannot be read inside the run (PMC counters need rocprofv3): it is PROFILE-DERIVED, from the
     # committed summary of `rocprofv3 --pmc` passes over this same command, and says so
-    for prof_name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for prof_name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         prof = os.path.join(ROOT, "profiles", prof_name)
         if os.path.exists(prof) and world == 1 and not fake:
             try:

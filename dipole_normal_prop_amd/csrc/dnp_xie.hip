@@ -231,9 +231,23 @@ __global__ __launch_bounds__(kOrderThreads) void xie_order_reg_kernel(const F* _
 // columns lane, lane + 64, ... ascending, then the butterfly over the lanes), the result rounded to F.  (Rounds 1-4 ran this
 // as a torch matmul - the one rocBLAS call on the path.)
 constexpr int kDotOrders = 5;           // the callers' `times` is odd: 1 or 5 visiting orders - one pass over the matrix for up to 5
-template <typename F>
+template <typename F, int VEC> struct DotVec;
+template <> struct DotVec<float, 4> { using T = float4; };
+template <> struct DotVec<double, 2> { using T = double2; };
+template <> struct DotVec<float, 1> { using T = float; };
+template <> struct DotVec<double, 1> { using T = double; };
+template <typename V, int VEC> __device__ __forceinline__ auto dot_elem(const V& v, int e) {
+    if constexpr (VEC == 1) return v;
+    else if constexpr (VEC == 2) return e == 0 ? v.x : v.y;
+    else return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
+}
+// VEC = elements per lane and load (16-byte loads when N is a multiple of VEC and the buffers are 16-byte aligned: 146 -> ~100 us
+// at N = 10^4 in fp32, profiles/r05_xie_time.txt; VEC = 1 is the general form).  A lane's columns: VEC consecutive ones per block
+// of 64 VEC, blocks ascending - a fixed order for given N and VEC.
+template <typename F, int VEC>
 __global__ __launch_bounds__(256) void xie_rowdots_kernel(const F* __restrict__ M, int64_t N, const F* __restrict__ weights,
                                                           int64_t R, int64_t r0, F* __restrict__ out) {
+    using V = typename DotVec<F, VEC>::T;
     constexpr int kDotRows = sizeof(F) == 4 ? 8 : 4;      // 40 / 20 fp64 sums per lane
     const int lane = threadIdx.x & 63;
     const int64_t i0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kDotRows;
@@ -244,16 +258,19 @@ __global__ __launch_bounds__(256) void xie_rowdots_kernel(const F* __restrict__ 
     for (int q = 0; q < kDotRows; ++q)
 #pragma unroll
         for (int r = 0; r < kDotOrders; ++r) s[q][r] = 0.0;
-    for (int64_t j = lane; j < N; j += 64) {
-        F w[kDotOrders], m[kDotRows];
+    for (int64_t j = (int64_t)lane * VEC; j < N; j += 64 * VEC) {
+        V w[kDotOrders], m[kDotRows];
 #pragma unroll
-        for (int r = 0; r < kDotOrders; ++r) w[r] = weights[(r0 + (r < nr ? r : 0)) * N + j];     // clamped: all loads unconditional
+        for (int r = 0; r < kDotOrders; ++r)              // clamped: all loads unconditional
+            w[r] = *reinterpret_cast<const V*>(weights + (r0 + (r < nr ? r : 0)) * N + j);
 #pragma unroll
-        for (int q = 0; q < kDotRows; ++q) m[q] = M[(i0 + q < N ? i0 + q : N - 1) * N + j];
+        for (int q = 0; q < kDotRows; ++q) m[q] = *reinterpret_cast<const V*>(M + (i0 + q < N ? i0 + q : N - 1) * N + j);
 #pragma unroll
-        for (int q = 0; q < kDotRows; ++q)
+        for (int e = 0; e < VEC; ++e)
 #pragma unroll
-            for (int r = 0; r < kDotOrders; ++r) s[q][r] += (double)(m[q] * w[r]);
+            for (int q = 0; q < kDotRows; ++q)
+#pragma unroll
+                for (int r = 0; r < kDotOrders; ++r) s[q][r] += (double)(dot_elem<V, VEC>(m[q], e) * dot_elem<V, VEC>(w[r], e));
     }
 #pragma unroll
     for (int q = 0; q < kDotRows; ++q)
@@ -316,8 +333,13 @@ static int run_xie_rowdots(const F* M, int64_t N, const F* weights, int64_t R, F
     DNP_REQUIRE(N >= 0 && R >= 0, "negative size");
     if (N == 0 || R == 0) return DNP_OK;
     DNP_REQUIRE(M && weights && out, "NULL pointer");
-    for (int64_t r0 = 0; r0 < R; r0 += kDotOrders)
-        hipLaunchKernelGGL(xie_rowdots_kernel<F>, dim3((unsigned)ceil_div(N, (int64_t)4 * (sizeof(F) == 4 ? 8 : 4))), dim3(256), 0, stream, M, N, weights, R, r0, out);
+    constexpr int kVec = sizeof(F) == 4 ? 4 : 2;
+    const bool wide = N % kVec == 0 && (reinterpret_cast<uintptr_t>(M) & 15) == 0 && (reinterpret_cast<uintptr_t>(weights) & 15) == 0;
+    const dim3 grid((unsigned)ceil_div(N, (int64_t)4 * (sizeof(F) == 4 ? 8 : 4)));
+    for (int64_t r0 = 0; r0 < R; r0 += kDotOrders) {
+        if (wide) hipLaunchKernelGGL((xie_rowdots_kernel<F, kVec>), grid, dim3(256), 0, stream, M, N, weights, R, r0, out);
+        else hipLaunchKernelGGL((xie_rowdots_kernel<F, 1>), grid, dim3(256), 0, stream, M, N, weights, R, r0, out);
+    }
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
 }

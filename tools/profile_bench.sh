@@ -4,7 +4,7 @@
 # kernel-trace stats, then the PMC passes in runs of their own (never combined with a trace domain other than
 # --kernel-trace).  tools/summarize_prof.py <round> turns the CSVs into the committed summaries under profiles/.
 set +e
-RND=${1:-r04}
+RND=${1:-r05}
 if [ -n "$2" ]; then export BENCH_FAKE_WORLD=$2; fi
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
