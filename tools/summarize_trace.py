@@ -51,11 +51,11 @@ print(f"# {path}")
 print(f"# {len(calls)} steady calls (first {skip} and the last dropped); call = from one launch of '{anchor}' to the next")
 print(f"# wall time per call: median {w:.1f} us (min {min(wall):.1f}, max {max(wall):.1f}); kernels busy {statistics.median(busy):.1f} us; "
       f"idle between kernels {w - statistics.median(busy):.1f} us")
-print(f"{'kernel':96s} {'n/call':>6s} {'med us':>9s} {'min us':>9s} {'us/call':>9s} {'share':>6s} {'VGPR':>4s} {'LDS':>6s} {'wgs':>8s}")
+print(f"{'kernel':96s} {'n/call':>6s} {'med us':>9s} {'min us':>9s} {'us/call':>9s} {'share':>6s} {'LDS':>6s} {'wgs':>8s}")
 table = []
 for k, d in per.items():
     n = statistics.median(d["n"])
     med = statistics.median(d["dur"])
     table.append((med * n, k, n, med, min(d["dur"]), d["vgpr"], d["lds"], d["wg"]))
 for tot, k, n, med, mn, vgpr, lds, wg in sorted(table, reverse=True):
-    print(f"{k:96s} {n:6.0f} {med:9.1f} {mn:9.1f} {tot:9.1f} {100 * tot / w:5.1f}% {vgpr:4d} {lds:6d} {wg:8d}")
+    print(f"{k:96s} {n:6.0f} {med:9.1f} {mn:9.1f} {tot:9.1f} {100 * tot / w:5.1f}% {lds:6d} {wg:8d}")
