@@ -216,13 +216,15 @@ int dnp_patch_fields_tiled_f64(const double* pts, int64_t N, int64_t ld_pts,
 size_t dnp_patch_exchange_bytes(int64_t N, int64_t split_patches);
 int dnp_exchange_init(void* exchange, size_t bytes, void* stream);
 /* The precondition of w_part, checked on the device for callers that cannot check it from patch sizes on the host (the
- * Python drivers do that: field_utils._tiles_within_two_groups): violations[0] (a device int32, NOT cleared here) += the
- * number of target tiles of dnp_patch_tile_rows() rows whose rows take three or more values of point_patch.  Nonzero means
- * w_part would be wrong for those tiles - use dnp_interactions_f32 on the slabs instead.  No synchronisation: read the
- * counter behind the stream.  (A -DDNP_BOUNDS build of the library checks the same inside the pair kernel.) */
+ * Python drivers do that: field_utils._tile_group_slots): violations[0] (a device int32, NOT cleared here) += the number of
+ * target tiles of dnp_patch_tile_rows() rows that break it for this w_slots - more than two values of point_patch with
+ * w_slots = 2; with w_slots = 3 more than three, or a third value while the second is not the first + 1.  Nonzero means w_part
+ * would be wrong for those tiles - use dnp_interactions_f32 / _f64 on the slabs instead.  No synchronisation: read the counter
+ * behind the stream.  (A -DDNP_BOUNDS build of the library checks the same inside the pair kernel.) */
 int dnp_check_tile_groups(const int64_t* point_patch, int64_t N, int w_slots, int32_t* violations, void* stream);
 /* W[k][j] = sum of w_part[k][i][slot] over the tiles i that overlap patch j (slot 0 when j is the patch of the tile's
- * first row), in tile order; W is [K, P] doubles.  Same quantity as dnp_interactions_f32 up to fp64 reassociation. */
+ * first row; otherwise slot 1 with w_slots = 2, and with w_slots = 3 slot 1 when j is that patch + 1, else slot 2), in tile
+ * order; W is [K, P] doubles.  Same quantity as dnp_interactions_f32 / _f64 up to fp64 reassociation. */
 int dnp_interactions_from_tiles(const double* w_part, int w_slots, int64_t K, int64_t N, const int64_t* point_patch,
                                 const int64_t* patch_off, int64_t P, double* W, void* stream);
 

