@@ -12,13 +12,13 @@ reference computes in the dtype it is handed (its socket path feeds fp64, util.p
 per-point, patch and representative drivers, the sharded driver and the xie ordered propagation; other dtypes are
 computed in fp32 and cast back.
 
-Reference lines each function mirrors are cited in its docstring.
+Reference lines each function mirrors are cited in its docstring.  The staging / warning / trace plumbing lives in _staging.py and
+the xie family in xie.py (round 5); every name they define is re-exported here, so `field_utils` remains the one module a caller of
+the reference binds.
 """
 from typing import List, Optional, Tuple
 
-import atexit
 import ctypes
-import threading
 
 import numpy as np
 import torch
@@ -47,218 +47,10 @@ SLAB_BLOCK_BYTES = 16 << 30
 SLAB_FREE_CHECK_BYTES = 1 << 30
 
 
-# ---------------------------------------------------------------------------------------------------
-# plumbing
-# ---------------------------------------------------------------------------------------------------
-def _compute_device() -> torch.device:
-    _lib.require_device()
-    return torch.device("cuda", torch.cuda.current_device())
-
-
-def _stage(t: torch.Tensor, dev: torch.device, dtype: torch.dtype) -> torch.Tensor:
-    """Tensor on the compute device with unit inner stride (rows may be strided)."""
-    if t.device != dev or t.dtype != dtype:
-        t = t.to(device=dev, dtype=dtype)
-    if t.dim() != 2:
-        raise ValueError(f"expected a 2-d point tensor, got shape {tuple(t.shape)}")
-    if t.shape[0] > 1 and (t.stride(1) != 1 or t.stride(0) < t.shape[1]):
-        t = t.contiguous()
-    elif t.shape[0] <= 1 and t.shape[1] > 1 and t.stride(1) != 1:
-        t = t.contiguous()
-    return t
-
-
-class _NullCtx:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        return False
-
-
-_NULL = _NullCtx()
-
-
-def _on_device(dev):
-    """torch.cuda.device(dev) only when dev is not already current (the context manager costs ~10 us)."""
-    return _NULL if dev.index is None or dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
-
-
-_tls = threading.local()
-
-
-def _workspace(nbytes: int, dev: torch.device, stream_handle=None) -> torch.Tensor:
-    """Scratch for one launch sequence, cached per (thread, device, stream): work on one stream is
-    ordered, so the next call on that stream may overwrite it; other streams / threads get their own."""
-    cache = getattr(_tls, "ws", None)
-    if cache is None:
-        cache = _tls.ws = {}
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream if stream_handle is None else stream_handle)
-    buf = cache.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = cache[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
-    return buf
-
-
-def _ld(t: torch.Tensor) -> int:
-    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
-
-
-def _work_dtype(*ts) -> torch.dtype:
-    return torch.float64 if any(t.dtype == torch.float64 for t in ts) else torch.float32
-
-
-def _idx(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
-    if t is None:
-        return None
-    return t.to(device=dev, dtype=torch.int64).contiguous()
-
-
-_WS_BYTES = {}
-
-
-def _pairs_into(kind: str, src, src_idx, tgt, tgt_idx, eps, max_pts, out, out_scatter=False, accumulate=False,
-                nonfinite=(None, None), stream_handle=None):
-    """Launch K1/K2 on staged device tensors.  src/tgt/out live on the compute device.  nonfinite = (device
-    pointer, pinned host pointer) of the three-int warning slot of this call, as ctypes pointers or None;
-    stream_handle = the device's current stream when the caller has looked it up already."""
-    lib = _lib.require_device()
-    S = src.shape[0] if src_idx is None else src_idx.shape[0]
-    T = tgt.shape[0] if tgt_idx is None else tgt_idx.shape[0]
-    f64 = src.dtype == torch.float64
-    nbytes = _WS_BYTES.get((kind, S, T, max_pts))
-    if nbytes is None:                                  # a pure function of the sizes: asked once per shape
-        if len(_WS_BYTES) > 4096:
-            _WS_BYTES.clear()
-        if kind == "field":
-            nbytes = lib.dnp_field_grad_workspace_bytes(S, T, max_pts)
-        else:
-            nbytes = lib.dnp_potential_workspace_bytes(S, T, max_pts)
-        _WS_BYTES[(kind, S, T, max_pts)] = nbytes
-    if stream_handle is None:
-        stream_handle = torch.cuda.current_stream(src.device).cuda_stream
-    ws = _workspace(nbytes, src.device, stream_handle)
-    with _on_device(src.device):
-        stream = ctypes.c_void_p(stream_handle)
-        if kind == "field":
-            fn = lib.dnp_field_grad_f64 if f64 else lib.dnp_field_grad_f32
-            rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(src_idx), _lib.ptr(tgt), T, _ld(tgt), _lib.ptr(tgt_idx),
-                    float(eps), int(max_pts), _lib.ptr(out), out.stride(0) if out.shape[0] > 1 else 3,
-                    int(bool(out_scatter)), int(bool(accumulate)), nonfinite[0], nonfinite[1], _lib.ptr(ws),
-                    ws.numel(), stream)
-        else:
-            fn = lib.dnp_potential_f64 if f64 else lib.dnp_potential_f32
-            rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(src_idx), _lib.ptr(tgt), T, _ld(tgt), _lib.ptr(tgt_idx),
-                    int(max_pts), _lib.ptr(out), 1, _lib.ptr(ws), nbytes, stream)
-    _lib.check(rc)
-    return out
-
-
-# ---- the reference's "warning: %d inf in field_grad" prints (field_utils.py:110-113) -----------------------------
-# The kernels count the Inf / NaN leaf components they zero into a three-int slot {inf, nan, spare} of a small
-# device ring, one slot per field_grad call.  Nothing is copied per call: after every _WARN_BATCH calls ONE
-# asynchronous copy moves that block of slots to pinned host memory behind the kernels (and re-arms the block), an
-# event says when it has landed, and the lines are printed by the next call on this thread that finds it landed -
-# at the latest by flush_warnings() or interpreter exit.  A field_grad call therefore never waits for the device,
-# and never launches a copy of its own, just to find out that there is nothing to warn about.
-_WARN_RING = 64
-_WARN_BATCH = 16
-
-
-class _WarnState:
-    def __init__(self, dev):
-        self.dev = dev
-        self.ring = torch.zeros((_WARN_RING, 3), dtype=torch.int32, device=dev)
-        self.host = torch.zeros((_WARN_RING, 3), dtype=torch.int32).pin_memory()
-        self.view = self.host.numpy()
-        self.dev_base = self.ring.data_ptr()
-        self.head = 0             # next slot to hand out
-        self.copied = 0           # slots below this have their copy to the host enqueued
-        self.tail = 0             # oldest slot not yet reported
-        self.batches = []         # (event, lo, hi) of the copies in flight, oldest first
-        self.stream = None        # stream of the calls since the last copy; False once they used more than one
-        self.lock = threading.Lock()   # flush_warnings() may drain this state from another thread
-        torch.cuda.current_stream(dev).synchronize()                  # the ring is initialised before its first use
-
-    def next_slot(self, stream):
-        """(device pointer, None) of the slot of one call launched on `stream` (an integer handle)."""
-        with self.lock:
-            full = self.head - self.tail >= _WARN_RING                # every slot is in flight: wait for the oldest
-        if full:
-            self.drain(block=True)
-        with self.lock:
-            i = self.head % _WARN_RING
-            self.head += 1
-            if self.stream is None:
-                self.stream = stream
-            elif self.stream != stream:
-                self.stream = False
-        return (ctypes.c_void_p(self.dev_base + 12 * i), None)
-
-    def _enqueue_copy(self):
-        """Copy slots [copied, head) to the host behind the kernels that fill them, re-arm them, remember the event."""
-        lo, hi = self.copied, self.head
-        if lo == hi:
-            return
-        with _on_device(self.dev):
-            if self.stream is False:                                  # calls on several streams: order them all first
-                torch.cuda.synchronize(self.dev)
-            a, b = lo % _WARN_RING, (hi - 1) % _WARN_RING + 1
-            for x, y in ([(a, b)] if a < b else [(a, _WARN_RING), (0, b)]):
-                self.host[x:y].copy_(self.ring[x:y], non_blocking=True)
-                self.ring[x:y].zero_()
-            ev = torch.cuda.Event()
-            ev.record()
-        self.batches.append((ev, lo, hi))
-        self.copied, self.stream = hi, None
-
-    def after_call(self):
-        with self.lock:
-            if self.head - self.copied >= _WARN_BATCH:
-                self._enqueue_copy()
-
-    def drain(self, block=False):
-        with self.lock:
-            if block:
-                torch.cuda.synchronize(self.dev)                      # also orders calls made on other streams
-                self._enqueue_copy()
-            while self.batches and (block or self.batches[0][0].query()):
-                ev, lo, hi = self.batches.pop(0)
-                ev.synchronize()
-                for k in range(lo, hi):
-                    n_inf, n_nan = int(self.view[k % _WARN_RING, 0]), int(self.view[k % _WARN_RING, 1])
-                    if n_inf:
-                        print("warning: %d inf in field_grad" % n_inf)
-                    if n_nan:
-                        print("warning: %d nan in field_grad" % n_nan)
-                self.tail = hi
-
-
-_warn_states = []
-_warn_lock = threading.Lock()
-
-
-def _warn_state(dev) -> _WarnState:
-    states = getattr(_tls, "warn", None)
-    if states is None:
-        states = _tls.warn = {}
-    st = states.get(dev.index)
-    if st is None:
-        st = states[dev.index] = _WarnState(dev)
-        with _warn_lock:
-            _warn_states.append(st)
-    return st
-
-
-def flush_warnings() -> None:
-    """Print every pending Inf/NaN warning of field_grad calls made so far (waits for the device)."""
-    with _warn_lock:
-        states = list(_warn_states)
-    for st in states:
-        st.drain(block=True)
-
-
-atexit.register(lambda: flush_warnings() if _warn_states else None)
+from ._staging import (_NULL, _WS_BYTES, _compute_device, _idx, _ld, _on_device, _pairs_into, _set_trace, _stage, _tls,  # noqa: F401
+                       _warn_state, _work_dtype, _workspace, flush_warnings, last_trace)
+from .xie import (_xie_knn_mask, _xie_pairs, align_votes, xie_distance, xie_field, xie_intersaction,  # noqa: F401
+                  xie_propagation_points_in_order, xie_propagation_points_onbfstree)
 
 
 def _field_like(kind, sources, means, eps, recursive, max_pts):
@@ -438,36 +230,6 @@ def _reference_field_fused(pc1, pc2):
         return None                      # a source / target set beyond one round of chunks: nothing was launched
     _lib.check(rc)
     return out if form == 1 else pc2
-
-
-# ---------------------------------------------------------------------------------------------------
-# traces
-# ---------------------------------------------------------------------------------------------------
-def _set_trace(kind: str, **items) -> None:
-    """Remember the visit order / flips / chosen interactions of the calling THREAD's last driver call.
-    Thread-local: the reference runs these drivers concurrently from Python threads (util.py:187-196,
-    :308-327).  Values may be device tensors; they are converted when somebody asks (last_trace)."""
-    store = getattr(_tls, "traces", None)
-    if store is None:
-        store = _tls.traces = {}
-    store[kind] = items
-
-
-def last_trace(kind: str) -> dict:
-    """Trace of this thread's last call of a greedy driver as numpy arrays.  kind: "patches"
-    (strongest_field_propagation), "reps" (..._reps), "points" (..._points), "sharded"
-    (parallel.sharded_patch_propagation).  Keys: order, sigma (+-1 per patch), chosen, start."""
-    items = getattr(_tls, "traces", {}).get(kind)
-    if items is None:
-        raise KeyError(f"no {kind!r} driver has run on this thread")
-    out = {}
-    for k, v in items.items():
-        if isinstance(v, torch.Tensor):
-            v = v.detach().cpu().numpy()
-            if v.ndim == 1 and v.shape[0] == 1 and k == "start":
-                v = int(v[0])
-        out[k] = v
-    return out
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -1344,161 +1106,3 @@ def _points_stepwise(work, diffuse, start):
         s = ((E * work[:, 3:]).sum(dim=-1) > 0).to(work.dtype) * 2 - 1
         work[:, 3:] = work[:, 3:] * s[:, None]
     return order
-
-
-# ---------------------------------------------------------------------------------------------------
-# the fork's "xie" pair functions (SURVEY section 8f-3)
-# ---------------------------------------------------------------------------------------------------
-def _xie_pairs(source, target, C, vector_out):
-    lib = _lib.require_device()
-    if source.dim() != 2 or source.shape[1] < 6 or target.dim() != 2 or target.shape[1] < 6:
-        raise ValueError("xie pair functions need [S,6] sources and [T,6] targets")
-    in_dev, in_dtype = target.device, torch.result_type(source, target)
-    dev = source.device if source.is_cuda else (target.device if target.is_cuda else _compute_device())
-    wd = _work_dtype(source, target)
-    src = _stage(source.detach(), dev, wd)
-    tgt = _stage(target.detach(), dev, wd)
-    S, T = src.shape[0], tgt.shape[0]
-    out = torch.empty((T, S, 3) if vector_out else (T, S), dtype=wd, device=dev)
-    if S and T:
-        fn = lib.dnp_xie_pairs_f64 if wd == torch.float64 else lib.dnp_xie_pairs_f32
-        with _on_device(dev):
-            rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(tgt), T, _ld(tgt), float(C), int(vector_out), _lib.ptr(out),
-                    _lib.current_stream())
-        _lib.check(rc)
-    return out.to(device=in_dev, dtype=in_dtype) if (out.device != in_dev or out.dtype != in_dtype) else out
-
-
-def _xie_knn_mask(source, target, k):
-    """[T,S] 0/1 mask: 1 where target t is among the k nearest targets of source s (the reference builds a
-    scipy KDTree on the targets and queries it with the sources, field_utils.py:451-460); brute force on the
-    tensors' device, distances in fp64."""
-    k = min(int(target.shape[0]), int(k))
-    sx, tx = source[:, :3].double(), target[:, :3].double()
-    mask = torch.zeros((target.shape[0], source.shape[0]), dtype=torch.float64, device=source.device)
-    step = max(1, (1 << 24) // max(int(target.shape[0]), 1))
-    for s0 in range(0, source.shape[0], step):
-        d2 = ((sx[s0:s0 + step, None, :] - tx[None, :, :]) ** 2).sum(dim=-1)          # [s, T]
-        nn = d2.topk(k, dim=1, largest=False).indices                                # [s, k]
-        cols = torch.arange(s0, s0 + nn.shape[0], device=source.device)[:, None].expand_as(nn)
-        mask[nn.reshape(-1), cols.reshape(-1)] = 1.0
-    return mask
-
-
-def xie_field(source: torch.Tensor, target: torch.Tensor, eps, max_pts=5000, knn_mask=-1, C=3):
-    """Reflected-normal pair field [T,S,3] (field_utils.py:431-469): (n_s - C (n_s.r^) r^)/|r|^3 with
-    r = x_s - x_t, left undivided for coincident pairs; optionally masked to the knn_mask nearest targets of
-    each source.  `eps` and `max_pts` are accepted and unused (the reference ignores eps; its recursion above
-    max_pts**2 pairs only bounds temporaries - and drops C / knn_mask on the way, which this does not)."""
-    with torch.no_grad():
-        out = _xie_pairs(source, target, C, True)
-        if knn_mask > 0:
-            out = out * _xie_knn_mask(source, target, knn_mask).to(out.device)[:, :, None]
-        return out
-
-
-def xie_intersaction(source: torch.Tensor, target: torch.Tensor, eps, knn_mask, C):
-    """[T,S] interaction matrix xie_field . n_t with NaN/Inf zeroed (field_utils.py:509-519)."""
-    with torch.no_grad():
-        if knn_mask > 0:
-            out = (xie_field(source, target, eps, knn_mask=knn_mask, C=C) * target[:, None, 3:]).sum(dim=-1)
-            out[out.isnan()] = 0
-            out[out.isinf()] = 0
-            return out
-        return _xie_pairs(source, target, C, False)
-
-
-def xie_distance(source: torch.Tensor, target: torch.Tensor, eps):
-    """sum_s |n_s * (x_s - x_t)| per target (field_utils.py:522-526); O(T*S*3) torch temporaries as there."""
-    R = source[None, :, :3] - target[:, None, :3]
-    return (source[None, :, 3:] * R).norm(dim=-1).sum(dim=-1)
-
-
-def xie_propagation_points_in_order(pts: torch.Tensor, eps, order, diffuse=False, verbose=False, points_weight=None,
-                                    knn_mask=-1, C=3):
-    """Ordered sign propagation (field_utils.py:569-605): for each of the T visiting orders in `order[T,N]`,
-    visit the points in that order, give every point the sign of the summed interaction with the points
-    visited before it, and return the [T,N] bool tensor `interactions < 0` (True = flipped).  `points_weight`
-    is accepted and has no effect, as in the reference (it multiplies by a tensor of ones)."""
-    lib = _lib.require_device()
-    with torch.no_grad():
-        dev = pts.device if pts.is_cuda else _compute_device()
-        # the reference computes in pts.dtype (interactions / weights are created with .type(pts.dtype), :581-586): a float64
-        # cloud (its socket path, socket_server_para.py:68-83) gets a float64 matrix and float64 row sums
-        wd = torch.float64 if pts.dtype == torch.float64 else torch.float32
-        work = pts.detach().to(device=dev, dtype=wd).contiguous()
-        order_t = torch.as_tensor(np.asarray(order)).to(device=dev, dtype=torch.int64).contiguous()
-        T, N = order_t.shape
-        M = xie_intersaction(work, work, eps, knn_mask, C).to(wd).contiguous()     # [N, N]
-        # no initialisation needed: the kernels zero `inter` themselves (an order row that repeats an index leaves points
-        # unvisited, and the reference's interactions start as torch.zeros) and write every weight
-        weights = torch.empty((T, N), dtype=wd, device=dev)
-        inter = torch.empty((T, N), dtype=wd, device=dev)
-        f64 = wd == torch.float64
-        with _on_device(dev):
-            rc = (lib.dnp_xie_order_f64 if f64 else lib.dnp_xie_order_f32)(_lib.ptr(M), N, _lib.ptr(order_t), T, _lib.ptr(weights),
-                                                                          _lib.ptr(inter), _lib.current_stream())
-        _lib.check(rc)
-        if diffuse:
-            # interactions[t][i] = sum_j M[i][j] * w[t][j] (:597-603): one pass over M for all T weight vectors
-            with _on_device(dev):
-                rc = (lib.dnp_xie_rowdots_f64 if f64 else lib.dnp_xie_rowdots_f32)(_lib.ptr(M), N, _lib.ptr(weights), T,
-                                                                                  _lib.ptr(inter), _lib.current_stream())
-            _lib.check(rc)
-        return (inter < 0).to(pts.device)
-
-
-def align_votes(flips: torch.Tensor) -> torch.Tensor:
-    """The vote alignment of field_utils.xie_propagation_points_onbfstree (field_utils.py:693-702), where the
-    reference calls gurobi (MIQP, :620-646) on a problem with one binary variable per visiting order: choose
-    x in {0,1}^T minimising  sum_ij [ H_ij if x_i == x_j else N - H_ij ]  with H_ij the Hamming distance between
-    the flip vectors of orders i and j (cal_w, :674-677; cal_loss, :606-617).  T is a handful (the `times` of the
-    caller, odd), so the optimum is found by enumerating all 2^(T-1) assignments with x_0 = 0 - the objective only
-    depends on which x are equal, so x and its complement tie and x_0 = 0 picks one of the two; further ties go
-    to the smallest assignment in binary order.  flips: [T, N] bool.  Returns x as a [T] bool tensor."""
-    T, N = flips.shape
-    if T > 20:
-        raise ValueError(f"{T} visiting orders: the exhaustive vote is meant for the reference's handful of orders")
-    f = flips.to(torch.float64)
-    H = (f[:, None, :] - f[None, :, :]).abs().sum(dim=-1).cpu().numpy()           # [T, T] Hamming distances
-    best_x, best_cost = 0, None
-    for code in range(1 << max(T - 1, 0)):
-        x = np.array([0] + [(code >> b) & 1 for b in range(T - 1)])
-        same = x[:, None] == x[None, :]
-        cost = float(np.where(same, H, N - H).sum())
-        if best_cost is None or cost < best_cost:
-            best_x, best_cost = x, cost
-    return torch.from_numpy(np.asarray(best_x, dtype=bool)).to(flips.device)
-
-
-def xie_propagation_points_onbfstree(pts: torch.Tensor, eps, diffuse=False, starting_point=0, verbose=False, k=10,
-                                     treshold=0.1, times=1, use_pw=False, knn_mask=-1, C=3):
-    """Propagation along breadth-first routes of the kNN graph with a vote over `times` routes
-    (field_utils.py:657-710): routes start at starting_point and at times-1 further points drawn with
-    np.random.seed(0) / randint as in the reference; every route is propagated in order
-    (xie_propagation_points_in_order: one interaction matrix, one persistent workgroup per route), the routes'
-    flip vectors are aligned (align_votes: the reference's MIQP, solved exactly without gurobi), and a point is
-    flipped when more than half of the aligned routes flip it.  `pts` normals are updated in place; returns the
-    [N] bool tensor of flipped points.  use_pw is accepted and has no effect (as points_weight in the reference)."""
-    assert times % 2 == 1 and times > 0
-    with torch.no_grad():
-        starts = [int(starting_point)]
-        np.random.seed(0)
-        while len(np.unique(starts)) < times:
-            cand = np.random.randint(0, pts.shape[0])
-            if cand not in starts:
-                starts.append(cand)
-        adj, _ = util.knn_graph(pts[:, :3].detach().cpu().numpy(), k, treshold)
-        orders = np.zeros((times, pts.shape[0]), dtype=np.int64)
-        for i in range(times):
-            orders[i] = util.bfs_route(adj, starts[i])
-        flips = xie_propagation_points_in_order(pts.clone(), eps, orders, diffuse, verbose=False, knn_mask=knn_mask,
-                                                C=C)                                   # [times, N]
-        status = align_votes(flips)
-        aligned = flips ^ status[:, None].to(flips.device)
-        cnts = aligned.sum(dim=0)
-        flipped = cnts > times / 2
-        sel = flipped.to(pts.device)
-        pts[sel, 3:] = pts[sel, 3:] * -1
-        _set_trace("bfstree", orders=orders, flips=flips, status=status, starts=np.array(starts))
-        return sel

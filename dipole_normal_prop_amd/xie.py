@@ -1,0 +1,166 @@
+"""The fork's "xie" pair functions of the reference's field_utils: xie_field / xie_intersaction / xie_distance
+(field_utils.py:431-526), the ordered sign propagation xie_propagation_points_in_order (:569-605) and the BFS-route propagation
+with its vote, xie_propagation_points_onbfstree (:657-710) - same names, argument order and defaults; the pair matrix, the ordered
+loop and its diffuse pass run in csrc/dnp_xie.hip behind the C ABI (dnp_xie_pairs_*, dnp_xie_order_*, dnp_xie_rowdots_*), in the
+cloud's own precision (float64 clouds in float64).  Split out of field_utils.py in round 5; every public name is re-exported there."""
+import numpy as np
+import torch
+
+from . import _lib
+from . import util
+from ._staging import _compute_device, _ld, _on_device, _set_trace, _stage, _work_dtype
+
+
+def _xie_pairs(source, target, C, vector_out):
+    lib = _lib.require_device()
+    if source.dim() != 2 or source.shape[1] < 6 or target.dim() != 2 or target.shape[1] < 6:
+        raise ValueError("xie pair functions need [S,6] sources and [T,6] targets")
+    in_dev, in_dtype = target.device, torch.result_type(source, target)
+    dev = source.device if source.is_cuda else (target.device if target.is_cuda else _compute_device())
+    wd = _work_dtype(source, target)
+    src = _stage(source.detach(), dev, wd)
+    tgt = _stage(target.detach(), dev, wd)
+    S, T = src.shape[0], tgt.shape[0]
+    out = torch.empty((T, S, 3) if vector_out else (T, S), dtype=wd, device=dev)
+    if S and T:
+        fn = lib.dnp_xie_pairs_f64 if wd == torch.float64 else lib.dnp_xie_pairs_f32
+        with _on_device(dev):
+            rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(tgt), T, _ld(tgt), float(C), int(vector_out), _lib.ptr(out),
+                    _lib.current_stream())
+        _lib.check(rc)
+    return out.to(device=in_dev, dtype=in_dtype) if (out.device != in_dev or out.dtype != in_dtype) else out
+
+
+def _xie_knn_mask(source, target, k):
+    """[T,S] 0/1 mask: 1 where target t is among the k nearest targets of source s (the reference builds a
+    scipy KDTree on the targets and queries it with the sources, field_utils.py:451-460); brute force on the
+    tensors' device, distances in fp64."""
+    k = min(int(target.shape[0]), int(k))
+    sx, tx = source[:, :3].double(), target[:, :3].double()
+    mask = torch.zeros((target.shape[0], source.shape[0]), dtype=torch.float64, device=source.device)
+    step = max(1, (1 << 24) // max(int(target.shape[0]), 1))
+    for s0 in range(0, source.shape[0], step):
+        d2 = ((sx[s0:s0 + step, None, :] - tx[None, :, :]) ** 2).sum(dim=-1)          # [s, T]
+        nn = d2.topk(k, dim=1, largest=False).indices                                # [s, k]
+        cols = torch.arange(s0, s0 + nn.shape[0], device=source.device)[:, None].expand_as(nn)
+        mask[nn.reshape(-1), cols.reshape(-1)] = 1.0
+    return mask
+
+
+def xie_field(source: torch.Tensor, target: torch.Tensor, eps, max_pts=5000, knn_mask=-1, C=3):
+    """Reflected-normal pair field [T,S,3] (field_utils.py:431-469): (n_s - C (n_s.r^) r^)/|r|^3 with
+    r = x_s - x_t, left undivided for coincident pairs; optionally masked to the knn_mask nearest targets of
+    each source.  `eps` and `max_pts` are accepted and unused (the reference ignores eps; its recursion above
+    max_pts**2 pairs only bounds temporaries - and drops C / knn_mask on the way, which this does not)."""
+    with torch.no_grad():
+        out = _xie_pairs(source, target, C, True)
+        if knn_mask > 0:
+            out = out * _xie_knn_mask(source, target, knn_mask).to(out.device)[:, :, None]
+        return out
+
+
+def xie_intersaction(source: torch.Tensor, target: torch.Tensor, eps, knn_mask, C):
+    """[T,S] interaction matrix xie_field . n_t with NaN/Inf zeroed (field_utils.py:509-519)."""
+    with torch.no_grad():
+        if knn_mask > 0:
+            out = (xie_field(source, target, eps, knn_mask=knn_mask, C=C) * target[:, None, 3:]).sum(dim=-1)
+            out[out.isnan()] = 0
+            out[out.isinf()] = 0
+            return out
+        return _xie_pairs(source, target, C, False)
+
+
+def xie_distance(source: torch.Tensor, target: torch.Tensor, eps):
+    """sum_s |n_s * (x_s - x_t)| per target (field_utils.py:522-526); O(T*S*3) torch temporaries as there."""
+    R = source[None, :, :3] - target[:, None, :3]
+    return (source[None, :, 3:] * R).norm(dim=-1).sum(dim=-1)
+
+
+def xie_propagation_points_in_order(pts: torch.Tensor, eps, order, diffuse=False, verbose=False, points_weight=None,
+                                    knn_mask=-1, C=3):
+    """Ordered sign propagation (field_utils.py:569-605): for each of the T visiting orders in `order[T,N]`,
+    visit the points in that order, give every point the sign of the summed interaction with the points
+    visited before it, and return the [T,N] bool tensor `interactions < 0` (True = flipped).  `points_weight`
+    is accepted and has no effect, as in the reference (it multiplies by a tensor of ones)."""
+    lib = _lib.require_device()
+    with torch.no_grad():
+        dev = pts.device if pts.is_cuda else _compute_device()
+        # the reference computes in pts.dtype (interactions / weights are created with .type(pts.dtype), :581-586): a float64
+        # cloud (its socket path, socket_server_para.py:68-83) gets a float64 matrix and float64 row sums
+        wd = torch.float64 if pts.dtype == torch.float64 else torch.float32
+        work = pts.detach().to(device=dev, dtype=wd).contiguous()
+        order_t = torch.as_tensor(np.asarray(order)).to(device=dev, dtype=torch.int64).contiguous()
+        T, N = order_t.shape
+        M = xie_intersaction(work, work, eps, knn_mask, C).to(wd).contiguous()     # [N, N]
+        # no initialisation needed: the kernels zero `inter` themselves (an order row that repeats an index leaves points
+        # unvisited, and the reference's interactions start as torch.zeros) and write every weight
+        weights = torch.empty((T, N), dtype=wd, device=dev)
+        inter = torch.empty((T, N), dtype=wd, device=dev)
+        f64 = wd == torch.float64
+        with _on_device(dev):
+            rc = (lib.dnp_xie_order_f64 if f64 else lib.dnp_xie_order_f32)(_lib.ptr(M), N, _lib.ptr(order_t), T, _lib.ptr(weights),
+                                                                          _lib.ptr(inter), _lib.current_stream())
+        _lib.check(rc)
+        if diffuse:
+            # interactions[t][i] = sum_j M[i][j] * w[t][j] (:597-603): one pass over M for all T weight vectors
+            with _on_device(dev):
+                rc = (lib.dnp_xie_rowdots_f64 if f64 else lib.dnp_xie_rowdots_f32)(_lib.ptr(M), N, _lib.ptr(weights), T,
+                                                                                  _lib.ptr(inter), _lib.current_stream())
+            _lib.check(rc)
+        return (inter < 0).to(pts.device)
+
+
+def align_votes(flips: torch.Tensor) -> torch.Tensor:
+    """The vote alignment of field_utils.xie_propagation_points_onbfstree (field_utils.py:693-702), where the
+    reference calls gurobi (MIQP, :620-646) on a problem with one binary variable per visiting order: choose
+    x in {0,1}^T minimising  sum_ij [ H_ij if x_i == x_j else N - H_ij ]  with H_ij the Hamming distance between
+    the flip vectors of orders i and j (cal_w, :674-677; cal_loss, :606-617).  T is a handful (the `times` of the
+    caller, odd), so the optimum is found by enumerating all 2^(T-1) assignments with x_0 = 0 - the objective only
+    depends on which x are equal, so x and its complement tie and x_0 = 0 picks one of the two; further ties go
+    to the smallest assignment in binary order.  flips: [T, N] bool.  Returns x as a [T] bool tensor."""
+    T, N = flips.shape
+    if T > 20:
+        raise ValueError(f"{T} visiting orders: the exhaustive vote is meant for the reference's handful of orders")
+    f = flips.to(torch.float64)
+    H = (f[:, None, :] - f[None, :, :]).abs().sum(dim=-1).cpu().numpy()           # [T, T] Hamming distances
+    best_x, best_cost = 0, None
+    for code in range(1 << max(T - 1, 0)):
+        x = np.array([0] + [(code >> b) & 1 for b in range(T - 1)])
+        same = x[:, None] == x[None, :]
+        cost = float(np.where(same, H, N - H).sum())
+        if best_cost is None or cost < best_cost:
+            best_x, best_cost = x, cost
+    return torch.from_numpy(np.asarray(best_x, dtype=bool)).to(flips.device)
+
+
+def xie_propagation_points_onbfstree(pts: torch.Tensor, eps, diffuse=False, starting_point=0, verbose=False, k=10,
+                                     treshold=0.1, times=1, use_pw=False, knn_mask=-1, C=3):
+    """Propagation along breadth-first routes of the kNN graph with a vote over `times` routes
+    (field_utils.py:657-710): routes start at starting_point and at times-1 further points drawn with
+    np.random.seed(0) / randint as in the reference; every route is propagated in order
+    (xie_propagation_points_in_order: one interaction matrix, one persistent workgroup per route), the routes'
+    flip vectors are aligned (align_votes: the reference's MIQP, solved exactly without gurobi), and a point is
+    flipped when more than half of the aligned routes flip it.  `pts` normals are updated in place; returns the
+    [N] bool tensor of flipped points.  use_pw is accepted and has no effect (as points_weight in the reference)."""
+    assert times % 2 == 1 and times > 0
+    with torch.no_grad():
+        starts = [int(starting_point)]
+        np.random.seed(0)
+        while len(np.unique(starts)) < times:
+            cand = np.random.randint(0, pts.shape[0])
+            if cand not in starts:
+                starts.append(cand)
+        adj, _ = util.knn_graph(pts[:, :3].detach().cpu().numpy(), k, treshold)
+        orders = np.zeros((times, pts.shape[0]), dtype=np.int64)
+        for i in range(times):
+            orders[i] = util.bfs_route(adj, starts[i])
+        flips = xie_propagation_points_in_order(pts.clone(), eps, orders, diffuse, verbose=False, knn_mask=knn_mask,
+                                                C=C)                                   # [times, N]
+        status = align_votes(flips)
+        aligned = flips ^ status[:, None].to(flips.device)
+        cnts = aligned.sum(dim=0)
+        flipped = cnts > times / 2
+        sel = flipped.to(pts.device)
+        pts[sel, 3:] = pts[sel, 3:] * -1
+        _set_trace("bfstree", orders=orders, flips=flips, status=status, starts=np.array(starts))
+        return sel
