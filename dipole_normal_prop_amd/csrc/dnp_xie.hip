@@ -129,9 +129,48 @@ __global__ __launch_bounds__(kXieBlock) void xie_pairs_kernel(const XieArgs<F> a
 
 constexpr int kOrderThreads = 1024;
 
+// Sum of a double over the 64 lanes of a wavefront as a wave-uniform value, register to register: four butterfly rounds on DPP
+// (quad_perm lane ^ 1, lane ^ 2, row_half_mirror, row_mirror) leave every 16-lane row's sum in all of its lanes, row_bcast:15 /
+// row_bcast:31 fold the four rows into lane 63, v_readlane makes it uniform.  The association is the balanced binary tree over the
+// lanes in index order (IEEE addition commutes, so the mirrored operand orders do not matter): v = v[0::2] + v[1::2], six times.
+// Rounds 3-4 reduced with six __shfl_down steps - six dependent ds_bpermute round trips, ~0.3 us of a 1.5-us step.
+template <int CTRL, int ROWMASK = 0xf>
+__device__ __forceinline__ double xie_dpp_f64(double v, double old) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v), o = __builtin_bit_cast(unsigned long long, old);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(o & 0xffffffffull), (int)(unsigned)(b & 0xffffffffull), CTRL, ROWMASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(b >> 32), CTRL, ROWMASK, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += xie_dpp_f64<0xB1>(v, v);                       // quad_perm [1,0,3,2]
+    v += xie_dpp_f64<0x4E>(v, v);                       // quad_perm [2,3,0,1]
+    v += xie_dpp_f64<0x141>(v, v);                      // row_half_mirror
+    v += xie_dpp_f64<0x140>(v, v);                      // row_mirror: every lane of a row holds the row's sum
+    v += xie_dpp_f64<0x142, 0xa>(v, 0.0);               // row_bcast:15 into rows 1 and 3 (rows 0 and 2 add 0)
+    v += xie_dpp_f64<0x143, 0xc>(v, 0.0);               // row_bcast:31 into rows 2 and 3: lane 63 = (r3 + r2) + (r1 + r0)
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffull), 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // F = the matrix's precision (float; double for float64 clouds, round 5): products rounded in F as the reference's
 // interaction_mat[idx] * weights, row sums in fp64, the sum rounded to F before its sign is taken.
-template <typename F>
+template <typename F, int VEC> struct DotVec;
+template <> struct DotVec<float, 4> { using T = float4; };
+template <> struct DotVec<double, 2> { using T = double2; };
+template <> struct DotVec<float, 1> { using T = float; };
+template <> struct DotVec<double, 1> { using T = double; };
+template <typename V, int VEC> __device__ __forceinline__ auto dot_elem(const V& v, int e) {
+    if constexpr (VEC == 1) return v;
+    else if constexpr (VEC == 2) return e == 0 ? v.x : v.y;
+    else return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
+}
+
+// VEC (both kernels): a thread owns its columns in groups of VEC consecutive ones - column j belongs to thread (j / VEC) % 1024 -, so
+// that the register form can fetch a row with 16-byte loads (VEC = 4 floats / 2 doubles when N is a multiple of VEC, else 1);
+// a thread adds its columns in ascending order.  The plain form uses the same ownership, so both forms sum in the same order.
+template <typename F, int VEC>
 __global__ __launch_bounds__(kOrderThreads) void xie_order_kernel(const F* __restrict__ M, int64_t N,
                                                                  const int64_t* __restrict__ order,
                                                                  F* __restrict__ weights,
@@ -147,8 +186,11 @@ __global__ __launch_bounds__(kOrderThreads) void xie_order_kernel(const F* __res
         const int64_t idx = ord[i];
         const F* row = M + idx * N;
         double s = 0.0;
-        for (int64_t j = tid; j < N; j += kOrderThreads) s += (double)(row[j] * w[j]);
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        for (int64_t j0 = (int64_t)tid * VEC; j0 < N; j0 += (int64_t)kOrderThreads * VEC)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (j0 + e < N) s += (double)(row[j0 + e] * w[j0 + e]);
+        s = wave_sum_f64(s);
         if (lane == 0) part[wave] = s;
         __syncthreads();
         if (tid == 0) {
@@ -162,8 +204,15 @@ __global__ __launch_bounds__(kOrderThreads) void xie_order_kernel(const F* __res
     }
 }
 
-// VPT columns per thread (N <= 1024 * VPT)
-template <typename F, int VPT>
+// VPT columns per thread (N <= 1024 * VPT).  DEPTH rows are in flight: the order is GIVEN, so every future row's address is known,
+// and a row of a 400 MB matrix visited in a scattered order comes from HBM (~2 us) - with ONE row ahead (rounds 3-4: cur / nxt)
+// a step could hide only its own ~0.5 us of reduction behind that; round 5 keeps a ring of DEPTH rows (3 in fp32, 2 in fp64:
+// the 128-VGPR budget of a 1024-thread workgroup), refilled slot by slot behind the step that consumed it.  Same products,
+// same fp64 additions in the same order as before (pinned bit for bit against the numpy statement of that order).
+#ifndef DNP_XIE_DEPTH
+#define DNP_XIE_DEPTH 3
+#endif
+template <typename F, int VPT, int DEPTH, int VEC>
 __global__ __launch_bounds__(kOrderThreads) void xie_order_reg_kernel(const F* __restrict__ M, int64_t N,
                                                                      const int64_t* __restrict__ order,
                                                                      F* __restrict__ weights,
@@ -172,53 +221,63 @@ __global__ __launch_bounds__(kOrderThreads) void xie_order_reg_kernel(const F* _
     const int64_t* ord = order + (int64_t)blockIdx.x * N;
     F* out = inter + (int64_t)blockIdx.x * N;
     __shared__ double part[2][kOrderThreads / 64];
-    F w[VPT], cur[VPT], nxt[VPT];
+    F w[VPT], buf[DEPTH][VPT];
 #pragma unroll
-    for (int k = 0; k < VPT; ++k) { w[k] = F(0); nxt[k] = F(0); }
+    for (int k = 0; k < VPT; ++k) w[k] = F(0);
     // interactions = torch.zeros(T, N) in the reference (field_utils.py:581): an order row that is not a full permutation
     // (a repeated index) leaves entries unvisited, and they must read 0, not whatever the caller's buffer held (round-3
     // advisor: field_utils passes torch.empty).  The stores of the loop below come after the loop's first barrier.
     for (int64_t j = tid; j < N; j += kOrderThreads) out[j] = F(0);
+    static_assert(VPT % VEC == 0, "whole groups of VEC columns per thread");
+    using V = typename DotVec<F, VEC>::T;
+    // slot k of a thread = column (k / VEC) * (VEC * 1024) + VEC * tid + k % VEC
+    auto column = [&](int k) -> int64_t { return (int64_t)(k / VEC) * (VEC * kOrderThreads) + (int64_t)VEC * tid + (k % VEC); };
     auto fetch = [&](int64_t idx, F (&dst)[VPT]) {
         const F* row = M + idx * N;
 #pragma unroll
-        for (int k = 0; k < VPT; ++k) {
-            const int64_t j = tid + (int64_t)k * kOrderThreads;
-            dst[k] = row[j < N ? j : N - 1];              // clamped, unconditional: all VPT loads in flight at once
+        for (int g = 0; g < VPT / VEC; ++g) {              // clamped, unconditional: all loads in flight at once (N % VEC == 0:
+            const int64_t j = column(g * VEC);             // a group lies inside the row or behind it as a whole)
+            const V v = *reinterpret_cast<const V*>(row + (j < N ? j : N - VEC));
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dst[g * VEC + e] = dot_elem<V, VEC>(v, e);
         }
     };
-    int64_t idx = ord[0];
-    fetch(idx, cur);
-    for (int64_t i = 0; i < N; ++i) {
-        const int64_t idx_next = i + 1 < N ? ord[i + 1] : idx;
-        if (i + 1 < N) fetch(idx_next, nxt);               // in flight while this row is reduced
-        double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < VPT; ++k)
-            if (tid + (int64_t)k * kOrderThreads < N) s += (double)(cur[k] * w[k]);
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        double* p = part[i & 1];
-        if (lane == 0) p[wave] = s;
-        __syncthreads();                                   // the only barrier of the step (partials double-buffered by parity)
-        double tot = 0.0;
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < N) fetch(ord[d], buf[d]);
+    for (int64_t i0 = 0; i0 < N; i0 += DEPTH) {
 #pragma unroll
-        for (int k = 0; k < kOrderThreads / 64; ++k) tot += p[k];
-        const F v = (F)tot;
-        const F sign = (v < F(0)) ? F(-1) : F(1);
-        if (tid == (int)(idx % kOrderThreads)) {
-            const int kk = (int)(idx / kOrderThreads);
+        for (int d = 0; d < DEPTH; ++d) {                  // slot d holds row i0 + d (static register indexing)
+            const int64_t i = i0 + d;
+            if (i < N) {                                    // uniform over the workgroup
+                const int64_t idx = ord[i];
+                double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < VPT; ++k) w[k] = (k == kk) ? sign : w[k];
+                for (int k = 0; k < VPT; ++k)
+                    if (column(k) < N) s += (double)(buf[d][k] * w[k]);
+                s = wave_sum_f64(s);
+                double* p = part[i & 1];
+                if (lane == 0) p[wave] = s;
+                __syncthreads();                           // the only barrier of the step (partials double-buffered by parity)
+                double tot = 0.0;
+#pragma unroll
+                for (int k = 0; k < kOrderThreads / 64; ++k) tot += p[k];
+                const F v = (F)tot;
+                const F sign = (v < F(0)) ? F(-1) : F(1);
+                if (tid == (int)((idx / VEC) % kOrderThreads)) {
+                    const int kk = (int)(idx / (VEC * kOrderThreads)) * VEC + (int)(idx % VEC);
+#pragma unroll
+                    for (int k = 0; k < VPT; ++k) w[k] = (k == kk) ? sign : w[k];
+                }
+                if (tid == 0) out[idx] = v;
+                if (i + DEPTH < N) fetch(ord[i + DEPTH], buf[d]);   // refill this slot: in flight under the next DEPTH - 1 steps
+            }
         }
-        if (tid == 0) out[idx] = v;
-#pragma unroll
-        for (int k = 0; k < VPT; ++k) cur[k] = nxt[k];
-        idx = idx_next;
     }
     F* wout = weights + (int64_t)blockIdx.x * N;
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
-        const int64_t j = tid + (int64_t)k * kOrderThreads;
+        const int64_t j = column(k);
         if (j < N) wout[j] = w[k];
     }
 }
@@ -231,16 +290,6 @@ __global__ __launch_bounds__(kOrderThreads) void xie_order_reg_kernel(const F* _
 // columns lane, lane + 64, ... ascending, then the butterfly over the lanes), the result rounded to F.  (Rounds 1-4 ran this
 // as a torch matmul - the one rocBLAS call on the path.)
 constexpr int kDotOrders = 5;           // the callers' `times` is odd: 1 or 5 visiting orders - one pass over the matrix for up to 5
-template <typename F, int VEC> struct DotVec;
-template <> struct DotVec<float, 4> { using T = float4; };
-template <> struct DotVec<double, 2> { using T = double2; };
-template <> struct DotVec<float, 1> { using T = float; };
-template <> struct DotVec<double, 1> { using T = double; };
-template <typename V, int VEC> __device__ __forceinline__ auto dot_elem(const V& v, int e) {
-    if constexpr (VEC == 1) return v;
-    else if constexpr (VEC == 2) return e == 0 ? v.x : v.y;
-    else return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
-}
 // VEC = elements per lane and load (16-byte loads when N is a multiple of VEC and the buffers are 16-byte aligned: 146 -> ~100 us
 // at N = 10^4 in fp32, profiles/r05_xie_time.txt; VEC = 1 is the general form).  A lane's columns: VEC consecutive ones per block
 // of 64 VEC, blocks ascending - a fixed order for given N and VEC.
@@ -315,14 +364,23 @@ static int run_xie_order(const F* M, int64_t N, const int64_t* order, int64_t R,
     // register form: the weights of a thread's columns live in VGPRs (1024 threads per workgroup: <= 128 VGPRs each, so
     // fp64 stops at 12 columns per thread)
     constexpr bool f64 = sizeof(F) == 8;
-    if (!DNP_XIE_ORDER_PLAIN && N <= 4 * kOrderThreads)
-        hipLaunchKernelGGL((xie_order_reg_kernel<F, 4>), dim3((unsigned)R), dim3(kOrderThreads), 0, stream, M, N, order, weights, inter);
-    else if (!DNP_XIE_ORDER_PLAIN && f64 && N <= 12 * kOrderThreads)
-        hipLaunchKernelGGL((xie_order_reg_kernel<F, f64 ? 12 : 16>), dim3((unsigned)R), dim3(kOrderThreads), 0, stream, M, N, order, weights, inter);
-    else if (!DNP_XIE_ORDER_PLAIN && !f64 && N <= 16 * kOrderThreads)
-        hipLaunchKernelGGL((xie_order_reg_kernel<F, 16>), dim3((unsigned)R), dim3(kOrderThreads), 0, stream, M, N, order, weights, inter);
-    else
-        hipLaunchKernelGGL(xie_order_kernel<F>, dim3((unsigned)R), dim3(kOrderThreads), 0, stream, M, N, order, weights, inter);
+    constexpr int kDepth = f64 ? 2 : DNP_XIE_DEPTH;        // rows in flight (VGPR budget: 128 per thread)
+    constexpr int kBig = f64 ? 12 : 16;                    // columns per thread of the large register form
+    constexpr int kVec = f64 ? 2 : 4;                      // 16-byte row loads when the rows allow (N % kVec == 0, M 16-byte aligned)
+    const bool wide = N % kVec == 0 && (reinterpret_cast<uintptr_t>(M) & 15) == 0;
+    const dim3 grid((unsigned)R), block(kOrderThreads);
+#define DNP_XIE_LAUNCH(KERNEL) hipLaunchKernelGGL((KERNEL), grid, block, 0, stream, M, N, order, weights, inter)
+    if (!DNP_XIE_ORDER_PLAIN && N <= 4 * kOrderThreads) {
+        if (wide) DNP_XIE_LAUNCH((xie_order_reg_kernel<F, 4, f64 ? 3 : 4, kVec>));
+        else DNP_XIE_LAUNCH((xie_order_reg_kernel<F, 4, f64 ? 3 : 4, 1>));
+    } else if (!DNP_XIE_ORDER_PLAIN && N <= kBig * kOrderThreads) {
+        if (wide) DNP_XIE_LAUNCH((xie_order_reg_kernel<F, kBig, kDepth, kVec>));
+        else DNP_XIE_LAUNCH((xie_order_reg_kernel<F, kBig, kDepth, 1>));
+    } else {
+        if (wide) DNP_XIE_LAUNCH((xie_order_kernel<F, kVec>));
+        else DNP_XIE_LAUNCH((xie_order_kernel<F, 1>));
+    }
+#undef DNP_XIE_LAUNCH
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
 }

@@ -271,22 +271,27 @@ def test_G21_float64_bfstree_vote(dev):
 
 def _order_spec(M, order, dtype):
     """The ordered propagation as specified (csrc/dnp_xie.hip): products rounded in the matrix's precision, fp64 sums - thread
-    t of 1024 adds its columns t, t + 1024, ... in ascending order, each wavefront folds its 64 sums by halving, the 16
+    t of 1024 adds its columns (groups of `vec` consecutive ones: column j belongs to thread (j // vec) % 1024) in ascending order, each wavefront folds its 64 sums as a balanced binary tree in lane order, the 16
     wavefront sums are added in order - and the sign of the total rounded to `dtype` becomes the weight.  Entries of points
     the order never visits stay 0."""
     N = M.shape[0]
-    pad = -(-N // 1024) * 1024
+    vec = 16 // M.dtype.itemsize                       # a thread owns its columns in groups of `vec` (16-byte row loads) ...
+    if N % vec:
+        vec = 1                                        # ... when the rows allow it
+    pad = -(-N // (1024 * vec)) * 1024 * vec
     w = np.zeros(N, dtype=dtype)
     inter = np.zeros(N, dtype=dtype)
     for idx in order:
         p = np.zeros(pad, dtype=np.float64)
         p[:N] = (M[idx] * w).astype(dtype)
         s = np.zeros(1024)
-        for k in range(pad // 1024):
-            s = s + p[k * 1024:(k + 1) * 1024]
+        groups = p.reshape(-1, 1024, vec)                  # [group][thread][element]: thread t adds its columns in ascending order
+        for gi in range(groups.shape[0]):
+            for e in range(vec):
+                s = s + groups[gi, :, e]
         v = s.reshape(16, 64).copy()
-        for off in (32, 16, 8, 4, 2, 1):
-            v[:, :off] = v[:, :off] + v[:, off:2 * off]
+        for _ in range(6):                                   # the wavefront's DPP butterfly: a balanced binary tree in lane order
+            v = v[:, 0::2] + v[:, 1::2]
         tot = 0.0
         for k in range(16):
             tot = tot + v[k, 0]

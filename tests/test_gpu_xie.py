@@ -126,21 +126,26 @@ def test_xie_pairs_are_the_ieee_op_order_bit_for_bit(dev, scale):
 
 def _order_kernel_spec(M, order):
     """dnp_xie_order_f32 as specified (csrc/dnp_xie.hip): fp32 products, fp64 sums - thread t of 1024 adds its columns
-    t, t + 1024, ... in ascending order, each wavefront folds its 64 sums by halving (lane l += lane l + off, off = 32 ... 1),
+    (groups of `vec` consecutive ones: column j belongs to thread (j // vec) % 1024) in ascending order, each wavefront folds its 64 sums as a balanced binary tree in lane order (the DPP butterfly of wave_sum_f64),
     the 16 wavefront sums are added in wavefront order - and the sign of the rounded fp32 total becomes the weight."""
     N = M.shape[0]
-    pad = -(-N // 1024) * 1024
+    vec = 16 // M.dtype.itemsize                       # a thread owns its columns in groups of `vec` (16-byte row loads) ...
+    if N % vec:
+        vec = 1                                        # ... when the rows allow it
+    pad = -(-N // (1024 * vec)) * 1024 * vec
     w = np.zeros(N, dtype=np.float32)
     inter = np.zeros(N, dtype=np.float32)
     for idx in order:
         p = np.zeros(pad, dtype=np.float64)
         p[:N] = (M[idx] * w).astype(np.float32)
         s = np.zeros(1024)
-        for k in range(pad // 1024):
-            s = s + p[k * 1024:(k + 1) * 1024]
+        groups = p.reshape(-1, 1024, vec)                  # [group][thread][element]: thread t adds its columns in ascending order
+        for gi in range(groups.shape[0]):
+            for e in range(vec):
+                s = s + groups[gi, :, e]
         v = s.reshape(16, 64).copy()
-        for off in (32, 16, 8, 4, 2, 1):
-            v[:, :off] = v[:, :off] + v[:, off:2 * off]
+        for _ in range(6):                                   # the wavefront's DPP butterfly: a balanced binary tree in lane order
+            v = v[:, 0::2] + v[:, 1::2]
         tot = 0.0
         for k in range(16):
             tot = tot + v[k, 0]
@@ -149,7 +154,7 @@ def _order_kernel_spec(M, order):
     return inter, w
 
 
-@pytest.mark.parametrize("n", [700, 1500, 5000])
+@pytest.mark.parametrize("n", [700, 701, 1500, 5000, 5001])
 def test_xie_order_kernel_is_its_specification_bit_for_bit(dev, n):
     """The register-resident, row-prefetching forms of the ordered propagation (round 3: 4 and 16 columns per thread)
     against the summation order they are specified to keep - inter and weights bit for bit, two orders at once."""

@@ -29,6 +29,12 @@ if not os.path.exists(PLAIN):
     build.build(extra_flags=["-DDNP_XIE_ORDER_PLAIN=1"], out=PLAIN, verbose=False)
 plain = ctypes.CDLL(PLAIN)
 plain.dnp_xie_order_f32.restype, plain.dnp_xie_order_f32.argtypes = _lib.SIGNATURES["dnp_xie_order_f32"]
+DEPTH2 = os.path.join(ROOT, "tools", "bin", "libdnp_xie_depth2.so")      # -DDNP_XIE_DEPTH=2: one row ahead, the form of rounds 3-4
+if not os.path.exists(DEPTH2):
+    from dipole_normal_prop_amd import build
+    build.build(extra_flags=["-DDNP_XIE_DEPTH=2"], out=DEPTH2, verbose=False)
+depth2 = ctypes.CDLL(DEPTH2)
+depth2.dnp_xie_order_f32.restype, depth2.dnp_xie_order_f32.argtypes = _lib.SIGNATURES["dnp_xie_order_f32"]
 
 
 def timed(fn, reps=20):
@@ -72,14 +78,16 @@ for n in (4000, 10000, 16000):
         ot = torch.from_numpy(orders.astype(np.int64)).to(dev)
         wts, itr = torch.empty((3, n), device=dev), torch.empty((3, n), device=dev)
         res = {}
-        for name, L in (("product (weights in registers, next row prefetched, one barrier)", lib), ("plain (-DDNP_XIE_ORDER_PLAIN=1)", plain)):
+        for name, L in (("product (weights in registers, three rows in flight, one barrier)", lib),
+                        ("two rows in flight (-DDNP_XIE_DEPTH=2, rounds 3-4)", depth2), ("plain (-DDNP_XIE_ORDER_PLAIN=1)", plain)):
             L.dnp_xie_order_f32(_lib.ptr(M), n, _lib.ptr(ot), 3, _lib.ptr(wts), _lib.ptr(itr), stream)
             torch.cuda.synchronize()
             res[name] = (wts.clone(), itr.clone())
             med, mn = timed(lambda: L.dnp_xie_order_f32(_lib.ptr(M), n, _lib.ptr(ot), 3, _lib.ptr(wts), _lib.ptr(itr), stream), reps=5)
             print(f"N={n:6d}   dnp_xie_order_f32 {name}: {mn:8.3f} ms = {mn * 1e3 / n:.2f} us per step")
-        (w1, i1), (w2, i2) = res.values()
-        print(f"N={n:6d}   weights and interactions bit-identical between the two forms: {bool(torch.equal(w1, w2) and torch.equal(i1, i2))}")
+        (w1, i1), (w2, i2), (w3, i3) = res.values()
+        print(f"N={n:6d}   weights and interactions bit-identical between the three forms: "
+              f"{bool(torch.equal(w1, w2) and torch.equal(i1, i2) and torch.equal(w1, w3) and torch.equal(i1, i3))}")
 
 # ---- round 5: the diffuse pass (dnp_xie_rowdots_*, one pass over M for all orders) against the torch matmul it replaced, the
 # kNN mask (brute-force top-k on the device, field_utils._xie_knn_mask) and the float64 forms
