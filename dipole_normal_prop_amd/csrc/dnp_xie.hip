@@ -186,10 +186,12 @@ __global__ __launch_bounds__(kOrderThreads) void xie_order_kernel(const F* __res
         const int64_t idx = ord[i];
         const F* row = M + idx * N;
         double s = 0.0;
-        for (int64_t j0 = (int64_t)tid * VEC; j0 < N; j0 += (int64_t)kOrderThreads * VEC)
+        using V = typename DotVec<F, VEC>::T;            // (N % VEC == 0: a group of VEC columns lies inside the row as a whole)
+        for (int64_t j0 = (int64_t)tid * VEC; j0 < N; j0 += (int64_t)kOrderThreads * VEC) {
+            const V rv = *reinterpret_cast<const V*>(row + j0), wv = *reinterpret_cast<const V*>(w + j0);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e)
-                if (j0 + e < N) s += (double)(row[j0 + e] * w[j0 + e]);
+            for (int e = 0; e < VEC; ++e) s += (double)(dot_elem<V, VEC>(rv, e) * dot_elem<V, VEC>(wv, e));
+        }
         s = wave_sum_f64(s);
         if (lane == 0) part[wave] = s;
         __syncthreads();
