@@ -44,8 +44,10 @@ SIGNATURES = {
     "dnp_tile_boxes_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
     "dnp_patch_fields_tiled_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64,
                                                   ctypes.c_float, _c_p, _c_p, ctypes.c_int, ctypes.c_int, _c_p, _c_sz, _c_p]),
-    "dnp_patch_fields_tiled_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64,
+    "dnp_patch_fields_tiled_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64,
                                                   ctypes.c_double, _c_p, _c_p, ctypes.c_int, _c_p]),
+    "dnp_patch_boxes_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p]),
+    "dnp_tile_boxes_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
     "dnp_patch_exchange_bytes": (_c_sz, [_c_i64, _c_i64]),
     "dnp_exchange_init": (ctypes.c_int, [_c_p, _c_sz, _c_p]),
     "dnp_check_tile_groups": (ctypes.c_int, [_c_p, _c_i64, ctypes.c_int, _c_p, _c_p]),

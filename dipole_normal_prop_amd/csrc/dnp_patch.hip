@@ -89,23 +89,24 @@ using namespace dnp;
 
 namespace dnp {
 // bounding boxes of the patches' points: boxes[p] = (min x, y, z, max x, y, z) - one workgroup per patch
-__global__ __launch_bounds__(256) void patch_box_kernel(const float* __restrict__ pts, int64_t ld,
+template <typename F>
+__global__ __launch_bounds__(256) void patch_box_kernel(const F* __restrict__ pts, int64_t ld,
                                                         const int64_t* __restrict__ off,
-                                                        const int64_t* __restrict__ idx, float* __restrict__ boxes) {
-    __shared__ float red[4][6];
+                                                        const int64_t* __restrict__ idx, F* __restrict__ boxes) {
+    __shared__ F red[4][6];
     const int64_t p = blockIdx.x;
-    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    F lo[3] = {F(3.0e38), F(3.0e38), F(3.0e38)}, hi[3] = {F(-3.0e38), F(-3.0e38), F(-3.0e38)};
     for (int64_t q = off[p] + threadIdx.x; q < off[p + 1]; q += 256) {
-        const float* r = pts + (idx ? idx[q] : q) * ld;
+        const F* r = pts + (idx ? idx[q] : q) * ld;
         for (int c = 0; c < 3; ++c) { lo[c] = r[c] < lo[c] ? r[c] : lo[c]; hi[c] = r[c] > hi[c] ? r[c] : hi[c]; }
     }
-    for (int c = 0; c < 3; ++c) { lo[c] = wave_min<float>(lo[c]); hi[c] = wave_max<float>(hi[c]); }
+    for (int c = 0; c < 3; ++c) { lo[c] = wave_min<F>(lo[c]); hi[c] = wave_max<F>(hi[c]); }
     if ((threadIdx.x & 63) == 0)
         for (int c = 0; c < 3; ++c) { red[threadIdx.x >> 6][c] = lo[c]; red[threadIdx.x >> 6][3 + c] = hi[c]; }
     __syncthreads();
     if (threadIdx.x < 3) {
         const int c = threadIdx.x;
-        float l = red[0][c], h = red[0][3 + c];
+        F l = red[0][c], h = red[0][3 + c];
         for (int w = 1; w < 4; ++w) { l = red[w][c] < l ? red[w][c] : l; h = red[w][3 + c] > h ? red[w][3 + c] : h; }
         boxes[p * 6 + c] = l;
         boxes[p * 6 + 3 + c] = h;
@@ -114,18 +115,19 @@ __global__ __launch_bounds__(256) void patch_box_kernel(const float* __restrict_
 
 // boxes of the target tiles: tile i = rows [i * rows_per_tile, (i + 1) * rows_per_tile) - what one wavefront of the
 // scalar-unit pair kernel owns (64 KT = 128 rows); one wavefront per tile
-__global__ __launch_bounds__(256) void tile_box_kernel(const float* __restrict__ pts, int64_t ld, int64_t N,
-                                                       int rows_per_tile, int64_t n_tiles, float* __restrict__ boxes) {
+template <typename F>
+__global__ __launch_bounds__(256) void tile_box_kernel(const F* __restrict__ pts, int64_t ld, int64_t N,
+                                                       int rows_per_tile, int64_t n_tiles, F* __restrict__ boxes) {
     const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= n_tiles) return;
     const int lane = threadIdx.x & 63;
-    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    F lo[3] = {F(3.0e38), F(3.0e38), F(3.0e38)}, hi[3] = {F(-3.0e38), F(-3.0e38), F(-3.0e38)};
     const int64_t r0 = tile * rows_per_tile, r1 = (r0 + rows_per_tile < N) ? r0 + rows_per_tile : N;
     for (int64_t q = r0 + lane; q < r1; q += 64) {
-        const float* r = pts + q * ld;
+        const F* r = pts + q * ld;
         for (int c = 0; c < 3; ++c) { lo[c] = r[c] < lo[c] ? r[c] : lo[c]; hi[c] = r[c] > hi[c] ? r[c] : hi[c]; }
     }
-    for (int c = 0; c < 3; ++c) { lo[c] = wave_min<float>(lo[c]); hi[c] = wave_max<float>(hi[c]); }
+    for (int c = 0; c < 3; ++c) { lo[c] = wave_min<F>(lo[c]); hi[c] = wave_max<F>(hi[c]); }
     if (lane == 0)
         for (int c = 0; c < 3; ++c) { boxes[tile * 6 + c] = lo[c]; boxes[tile * 6 + 3 + c] = hi[c]; }
 }
@@ -198,7 +200,21 @@ int dnp_tile_boxes_f32(const float* pts, int64_t N, int64_t ld_pts, int64_t rows
     DNP_REQUIRE(pts && boxes, "NULL pointer");
     DNP_REQUIRE(ld_pts >= 3, "ld_pts=%lld < 3", (long long)ld_pts);
     const int64_t n_tiles = ceil_div(N, rows_per_tile);
-    hipLaunchKernelGGL(tile_box_kernel, dim3((unsigned)ceil_div(n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, pts, ld_pts,
+    hipLaunchKernelGGL(tile_box_kernel<float>, dim3((unsigned)ceil_div(n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, pts, ld_pts,
+                       N, (int)rows_per_tile, n_tiles, boxes);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+int dnp_tile_boxes_f64(const double* pts, int64_t N, int64_t ld_pts, int64_t rows_per_tile, double* boxes, void* stream) {
+    clear_error();
+    DNP_REQUIRE(N >= 0, "negative size");
+    DNP_REQUIRE(rows_per_tile > 0 && rows_per_tile <= 1 << 20, "rows_per_tile=%lld", (long long)rows_per_tile);
+    if (N == 0) return DNP_OK;
+    DNP_REQUIRE(pts && boxes, "NULL pointer");
+    DNP_REQUIRE(ld_pts >= 3, "ld_pts=%lld < 3", (long long)ld_pts);
+    const int64_t n_tiles = ceil_div(N, rows_per_tile);
+    hipLaunchKernelGGL(tile_box_kernel<double>, dim3((unsigned)ceil_div(n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, pts, ld_pts,
                        N, (int)rows_per_tile, n_tiles, boxes);
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
@@ -228,7 +244,20 @@ int dnp_patch_boxes_f32(const float* pts, int64_t N, int64_t ld_pts, const int64
     if (P == 0) return DNP_OK;
     DNP_REQUIRE(pts && patch_off && boxes, "NULL pointer");               // patch_idx may be NULL (contiguous)
     DNP_REQUIRE(ld_pts >= 3, "ld_pts=%lld < 3", (long long)ld_pts);
-    hipLaunchKernelGGL(patch_box_kernel, dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pts, ld_pts, patch_off,
+    hipLaunchKernelGGL(patch_box_kernel<float>, dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pts, ld_pts, patch_off,
+                       patch_idx, boxes);
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+int dnp_patch_boxes_f64(const double* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
+                        const int64_t* patch_idx, int64_t P, double* boxes, void* stream) {
+    clear_error();
+    DNP_REQUIRE(N >= 0 && P >= 0, "negative size");
+    if (P == 0) return DNP_OK;
+    DNP_REQUIRE(pts && patch_off && boxes, "NULL pointer");               // patch_idx may be NULL (contiguous)
+    DNP_REQUIRE(ld_pts >= 3, "ld_pts=%lld < 3", (long long)ld_pts);
+    hipLaunchKernelGGL(patch_box_kernel<double>, dim3((unsigned)P), dim3(256), 0, (hipStream_t)stream, pts, ld_pts, patch_off,
                        patch_idx, boxes);
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
@@ -381,9 +410,10 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
 
 // ---- the same slabs for a FLOAT64 cloud (round 5): the reference computes in the dtype it is handed (field_utils.py:96-109) and
 // its socket path hands it float64 (util.py:71-77), so a float64 cloud's patch fields, interaction sums and diffuse field
-// are evaluated in double - no far-field chain (its truncation is an fp32-ulp device), hence no box tables and no split tail;
-// the scalar-unit kernel at KT = 2 on the patch-sorted layout (two-wavefront workgroups, XCD-aware tile mapping, interaction
-// partials out of the epilogue), the LDS kernel for gathered patches and for eps <= 0.
+// are evaluated in double: the scalar-unit kernel at KT = 2 on the patch-sorted layout (two-wavefront workgroups, XCD-aware
+// tile mapping, interaction partials out of the epilogue), the LDS kernel for gathered patches and for eps <= 0.  With both box
+// tables (dnp_patch_boxes_f64, dnp_tile_boxes_f64) a (wavefront, patch) whose boxes are far apart runs the fp64 far chain (one
+// transcendental, the series to e^4: pair_kernel.h, kFarRatio64); no split tail in this precision.
 #ifndef DNP_KT64
 #define DNP_KT64 2
 #endif
@@ -392,6 +422,7 @@ static_assert(kPatchScalarKT64 == kPatchScalarKT, "w_part tiles of both precisio
 
 int dnp_patch_fields_tiled_f64(const double* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
                                const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
+                               const double* patch_box, const double* tile_box,
                                int64_t p_begin, int64_t p_end, double eps, double* dE, double* w_part, int w_slots, void* stream) {
     clear_error();
     DNP_REQUIRE(!w_part || w_slots == 2 || w_slots == 3, "w_slots=%d (2 or 3 group slots per tile)", w_slots);
@@ -412,25 +443,27 @@ int dnp_patch_fields_tiled_f64(const double* pts, int64_t N, int64_t ld_pts, con
         pa.tgt = pts; pa.ld_tgt = ld_pts; pa.tgt_idx = nullptr; pa.T = N;
         pa.chunk_off_dev = patch_off; pa.chunk_base = p_begin + k0; pa.tgt_group = point_patch;
         pa.eps = eps; pa.partial = dE + k0 * N * 3;
-        pa.far_d2 = 0.0;
+        const bool tabled = scalar_path && patch_box && tile_box && far_threshold_d2(eps, kFarRatio64) > 0.0;
+        pa.far_d2 = tabled ? far_threshold_d2(eps, kFarRatio64) : 0.0;
+        pa.chunk_box = tabled ? patch_box : nullptr;
+        pa.tile_box = tabled ? tile_box : nullptr;
         pa.w_part = w_part ? w_part + k0 * n_tiles * w_slots : nullptr;
         const hipStream_t st = (hipStream_t)stream;
 #ifdef DNP_BOUNDS
         pa.bnd = PairBounds{};
         pa.bnd.n_chunk_off = P + 1; pa.bnd.n_tgt_group = N; pa.bnd.n_w_part = w_part ? kn * n_tiles * w_slots : 0;
+        pa.bnd.n_chunk_box = tabled ? P : 0; pa.bnd.n_tile_box = tabled ? n_tiles : 0;
         pa.bnd.n_partial = kn * N * 3; pa.bnd.n_src_rows = N; pa.bnd.err = bounds_err_buffer();
 #endif
         if (scalar_path) {
             const dim3 sgrid((unsigned)ceil_div(N, (int64_t)kTabledWaves * 64 * kPatchScalarKT64), (unsigned)kn);
-            if (w_part && w_slots == 3)
-                hipLaunchKernelGGL((pair_kernel_scalar<double, double, kField, kPatchScalarKT64, kFast, false, false, false, 3, 1, kTabledWaves>),
-                                   sgrid, dim3(kTabledWaves * 64), 0, st, pa);
-            else if (w_part)
-                hipLaunchKernelGGL((pair_kernel_scalar<double, double, kField, kPatchScalarKT64, kFast, false, false, false, 2, 1, kTabledWaves>),
-                                   sgrid, dim3(kTabledWaves * 64), 0, st, pa);
-            else
-                hipLaunchKernelGGL((pair_kernel_scalar<double, double, kField, kPatchScalarKT64, kFast, false, false, false, 0, 1, kTabledWaves>),
-                                   sgrid, dim3(kTabledWaves * 64), 0, st, pa);
+#define DNP_LAUNCH_F64(FARF, WP)                                                                                              \
+    hipLaunchKernelGGL((pair_kernel_scalar<double, double, kField, kPatchScalarKT64, kFast, FARF, FARF, FARF, WP, 1, kTabledWaves>), \
+                       sgrid, dim3(kTabledWaves * 64), 0, st, pa)
+            const int wp = w_part ? w_slots : 0;
+            if (tabled) { if (wp == 3) DNP_LAUNCH_F64(true, 3); else if (wp == 2) DNP_LAUNCH_F64(true, 2); else DNP_LAUNCH_F64(true, 0); }
+            else { if (wp == 3) DNP_LAUNCH_F64(false, 3); else if (wp == 2) DNP_LAUNCH_F64(false, 2); else DNP_LAUNCH_F64(false, 0); }
+#undef DNP_LAUNCH_F64
         } else {
             const dim3 grid((unsigned)ceil_div(N, (int64_t)kBlock), (unsigned)kn);     // KT = 1: 116 VGPRs (KT = 4: 220, two wavefronts per SIMD)
             if (eps > 0.0)

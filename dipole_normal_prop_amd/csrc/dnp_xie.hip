@@ -369,7 +369,7 @@ static int run_xie_order(const F* M, int64_t N, const int64_t* order, int64_t R,
     constexpr int kDepth = f64 ? 2 : DNP_XIE_DEPTH;        // rows in flight (VGPR budget: 128 per thread)
     constexpr int kBig = f64 ? 12 : 16;                    // columns per thread of the large register form
     constexpr int kVec = f64 ? 2 : 4;                      // 16-byte row loads when the rows allow (N % kVec == 0, M 16-byte aligned)
-    const bool wide = N % kVec == 0 && (reinterpret_cast<uintptr_t>(M) & 15) == 0;
+    const bool wide = N % kVec == 0 && (reinterpret_cast<uintptr_t>(M) & 15) == 0 && (reinterpret_cast<uintptr_t>(weights) & 15) == 0;
     const dim3 grid((unsigned)R), block(kOrderThreads);
 #define DNP_XIE_LAUNCH(KERNEL) hipLaunchKernelGGL((KERNEL), grid, block, 0, stream, M, N, order, weights, inter)
     if (!DNP_XIE_ORDER_PLAIN && N <= 4 * kOrderThreads) {

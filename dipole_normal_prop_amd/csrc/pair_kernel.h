@@ -318,8 +318,12 @@ constexpr double kFarRatio = DNP_FAR_RATIO;
 // threshold: for a tiny eps (< 1e-30) far_d2 would admit pairs whose u^3 = rsq(d2)^3 overflows fp32 (then e = eps*inf
 // and w = NaN where the exact chain returns a finite 1/(|r|^3+eps)), so such calls keep the exact chain.
 constexpr double kFarMinEps = 1e-30;
-static inline double far_threshold_d2(double eps) {
-    return eps >= kFarMinEps ? __builtin_pow(eps / kFarRatio, 2.0 / 3.0) : 0.0;
+// fp64 (round 5): ONE far tier with the series taken to e^4 - 1/(1 + e) = 1 - e + e^2 - e^3 + e^4 - ..., truncation e^5 < 7.8e-17
+// (below half an fp64 ulp) for e = eps / |r|^3 < kFarRatio64 = 6e-4, i.e. boxes farther apart than 0.255 for eps = 1e-5: the
+// fp64 chain's second transcendental (v_rcp_f64, 16 cycles + 3 refinement instructions) becomes 4 fused multiply-adds.
+constexpr double kFarRatio64 = 6e-4;
+static inline double far_threshold_d2(double eps, double ratio = kFarRatio) {
+    return eps >= kFarMinEps ? __builtin_pow(eps / ratio, 2.0 / 3.0) : 0.0;
 }
 
 template <typename F>
@@ -329,11 +333,17 @@ __device__ __forceinline__ void pair_field_far(F sx, F sy, F sz, F px, F py, F p
     const F rx = sx - tx, ry = sy - ty, rz = sz - tz;
     const F d2 = M::fma(rz, rz, M::fma(ry, ry, rx * rx));
     const F pr = M::fma(pz, rz, M::fma(py, ry, px * rx));
-    const F u = M::rsq(d2);
+    const F u = M::rsq_fast(d2);                    // (fp32: the hardware's v_rsq_f32; fp64: v_rsq_f64 + one third-order step)
     const F u2 = u * u;
     const F u3 = u2 * u;
     const F e = eps * u3;
-    const F w = M::fma(u3, M::fma(e, e, -e), u3);
+    F w;
+    if constexpr (sizeof(F) == 8) {                 // fp64: the series to e^4 (see kFarRatio64)
+        const F t = M::fma(e, M::fma(e, M::fma(e, e - F(1), F(1)), F(-1)), F(1));
+        w = u3 * t;
+    } else {
+        w = M::fma(u3, M::fma(e, e, -e), u3);
+    }
     const F a = pr * (w * u2);
     ax = M::fma(a, rx, ax);
     ay = M::fma(a, ry, ay);
@@ -898,7 +908,8 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
         static_assert(kFarRatio == 8e-3 && kFar2Ratio == 7e-4, "DNP_FAR2_SCALE is (kFarRatio / kFar2Ratio)^(2/3) = 5.0736 for these");
 #endif
         constexpr F kFar2Scale = (F)DNP_FAR2_SCALE;
-        far_chunk = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2) + (int)(d2box > a.far_d2 * kFar2Scale));
+        if constexpr (sizeof(F) == 8) far_chunk = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2));     // fp64: one tier
+        else far_chunk = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2) + (int)(d2box > a.far_d2 * kFar2Scale));
 #else
         far_chunk = __builtin_amdgcn_readfirstlane((int)(d2box > a.far_d2));
 #endif

@@ -318,14 +318,15 @@ def _disjoint(idx: torch.Tensor, n: int) -> bool:
 
 
 def _patch_boxes(work: torch.Tensor, off, idx) -> torch.Tensor:
-    """[P, 6] bounding boxes (min xyz, max xyz) of the patches' points (dnp_patch_boxes_f32): what the pair kernel's
-    far-field test compares a wavefront's targets with; computed once per cloud."""
+    """[P, 6] bounding boxes (min xyz, max xyz) of the patches' points (dnp_patch_boxes_f32 / _f64, in the cloud's precision):
+    what the pair kernel's far-field test compares a wavefront's targets with; computed once per cloud."""
     lib = _lib.require_device()
     P = off.shape[0] - 1
-    boxes = torch.empty((P, 6), dtype=torch.float32, device=work.device)
+    boxes = torch.empty((P, 6), dtype=work.dtype, device=work.device)
+    fn = lib.dnp_patch_boxes_f64 if work.dtype == torch.float64 else lib.dnp_patch_boxes_f32
     with _on_device(work.device):
-        rc = lib.dnp_patch_boxes_f32(_lib.ptr(work), work.shape[0], work.stride(0), _lib.ptr(off), _lib.ptr(idx), P,
-                                     _lib.ptr(boxes), _lib.current_stream())
+        rc = fn(_lib.ptr(work), work.shape[0], work.stride(0), _lib.ptr(off), _lib.ptr(idx), P, _lib.ptr(boxes),
+                _lib.current_stream())
     _lib.check(rc)
     return boxes
 
@@ -369,10 +370,12 @@ def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, ep
     N = work.shape[0]
     dE = torch.empty((p1 - p0, N, 3), dtype=work.dtype, device=work.device)
     if work.dtype == torch.float64:
-        # a float64 cloud: double-precision slabs (no far-field chain in this precision: no box tables, no split tail)
+        # a float64 cloud: double-precision slabs (the fp64 far chain when both box tables are given; no split tail)
+        both = boxes is not None and tile_boxes is not None
         with _on_device(work.device):
             rc = lib.dnp_patch_fields_tiled_f64(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
-                                                off.shape[0] - 1, _lib.ptr(point_patch), p0, p1, float(eps), _lib.ptr(dE),
+                                                off.shape[0] - 1, _lib.ptr(point_patch), _lib.ptr(boxes if both else None),
+                                                _lib.ptr(tile_boxes if both else None), p0, p1, float(eps), _lib.ptr(dE),
                                                 _lib.ptr(w_part), 2 if w_part is None else int(w_part.shape[-1]),
                                                 _lib.current_stream())
         _lib.check(rc)
@@ -433,12 +436,10 @@ class _TileTables:
         N = swork.shape[0]
         self.rows = int(lib.dnp_patch_tile_rows())
         self.n_tiles = -(-N // self.rows)
-        self.boxes = None                                   # float64 clouds run without the far-field chain: no box table
-        if swork.dtype == torch.float32:
-            self.boxes = torch.empty((self.n_tiles, 6), dtype=torch.float32, device=swork.device)
-            with _on_device(swork.device):
-                _lib.check(lib.dnp_tile_boxes_f32(_lib.ptr(swork), N, swork.stride(0), self.rows, _lib.ptr(self.boxes),
-                                                  _lib.current_stream()))
+        self.boxes = torch.empty((self.n_tiles, 6), dtype=swork.dtype, device=swork.device)      # in the cloud's precision
+        fn = lib.dnp_tile_boxes_f64 if swork.dtype == torch.float64 else lib.dnp_tile_boxes_f32
+        with _on_device(swork.device):
+            _lib.check(fn(_lib.ptr(swork), N, swork.stride(0), self.rows, _lib.ptr(self.boxes), _lib.current_stream()))
         self.slots = _tile_group_slots(sizes, N, self.rows)        # 2 / 3 group slots per tile, 0 = not fusable
         self.fused = self.slots != 0
 
@@ -702,7 +703,7 @@ def _batched_begin(work: torch.Tensor, patches, diffuse: bool, eps: float = 1e-5
     # are evaluated by one launch and kept for the diffuse combine.  Beyond it the budget is raised to 80 % of what
     # the device has free (288 GB of HBM on an MI355X), the patches go through in blocks of at most SLAB_BLOCK_BYTES,
     # as many blocks as fit are kept, and only the others are evaluated a second time for the combine.
-    boxes = _patch_boxes(swork, off, None) if swork.dtype == torch.float32 else None   # far-field test of the fp32 pair kernel
+    boxes = _patch_boxes(swork, off, None)               # for the far-field test of the pair kernel
     tiles = _TileTables(swork, sizes)                    # target-tile boxes; can W come out of the kernel's epilogue?
     per_slab = N * 3 * swork.element_size()
     n_local = max(p_hi - p_lo, 1)

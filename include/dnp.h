@@ -206,12 +206,20 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts,
  * socket path hands it float64, util.py:71-77), so on a float64 cloud the greedy drivers' per-patch fields (field_utils.py:
  * 328-331, :258-265), interaction sums (:316, :244) and diffuse field are double precision here too.  dE is [p_end - p_begin, N, 3]
  * doubles; w_part as above (the per-point dot taken in fp64), same precondition (dnp_check_tile_groups), tiles of
- * dnp_patch_tile_rows() rows.  No far-field chain in this precision (its truncation error is an fp32 ulp), hence no box tables
- * and no split tail: the scalar-unit kernel on the patch-sorted layout (patch_idx == NULL, eps > 0), the LDS kernel otherwise
- * (w_part must be NULL then).  Within ~1e-15 of the reference's float64 arithmetic per pair (refined v_rsq_f64 / v_rcp_f64). */
+ * dnp_patch_tile_rows() rows.  The scalar-unit kernel on the patch-sorted layout (patch_idx == NULL, eps > 0), the LDS kernel
+ * otherwise (w_part must be NULL then).  patch_box / tile_box (both or neither; [P][6] / [ceil(N / R)][6] doubles from
+ * dnp_patch_boxes_f64 / dnp_tile_boxes_f64; NULL = every pair through the exact chain): a (wavefront, patch) whose boxes are farther
+ * apart than (eps / 6e-4)^(1/3) runs the fp64 far chain - 1 / (|r|^3 + eps) = u^3 (1 - e + e^2 - e^3 + e^4), e = eps u^3 < 6e-4,
+ * truncation < 7.8e-17: one transcendental instead of two; results agree with the exact chain to fp64 rounding.  No split tail
+ * in this precision.  Within ~1e-15 of the reference's float64 arithmetic per pair (refined v_rsq_f64 / v_rcp_f64). */
+int dnp_patch_boxes_f64(const double* pts, int64_t N, int64_t ld_pts,
+                        const int64_t* patch_off, const int64_t* patch_idx, int64_t P,
+                        double* boxes, void* stream);
+int dnp_tile_boxes_f64(const double* pts, int64_t N, int64_t ld_pts, int64_t rows_per_tile, double* boxes, void* stream);
 int dnp_patch_fields_tiled_f64(const double* pts, int64_t N, int64_t ld_pts,
                                const int64_t* patch_off, const int64_t* patch_idx, int64_t P,
-                               const int64_t* point_patch, int64_t p_begin, int64_t p_end, double eps,
+                               const int64_t* point_patch, const double* patch_box, const double* tile_box,
+                               int64_t p_begin, int64_t p_end, double eps,
                                double* dE, double* w_part, int w_slots, void* stream);
 size_t dnp_patch_exchange_bytes(int64_t N, int64_t split_patches);
 int dnp_exchange_init(void* exchange, size_t bytes, void* stream);

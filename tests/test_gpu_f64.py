@@ -101,7 +101,7 @@ def test_f64_patch_slabs_interactions_and_combine(dev):
     swork = pts[idx].contiguous()
     sorted_patch = point_patch[idx].contiguous()
     tiles = fu._TileTables(swork, sizes)
-    assert tiles.boxes is None                                          # no far-field chain in fp64
+    assert tiles.boxes.dtype == torch.float64                           # box tables in the cloud's precision (the fp64 far chain)
     ranges_off = off
     dS, W = fu._slabs_and_rows(swork, ranges_off, sorted_patch, 0, P, 1e-5, None, tiles, sizes)
     assert dS.dtype == torch.float64
@@ -160,6 +160,33 @@ def test_f64_interaction_partials_out_of_the_epilogue(dev):
         fu.strongest_field_propagation(b, list(enumerate(ranges)), ranges, diffuse=True)
     tr_b = fu.last_trace("patches")
     assert np.array_equal(tr_a["order"], tr_b["order"]) and torch.equal(a, b)
+
+
+def test_f64_far_chain_on_the_bench_cloud(dev):
+    """The fp64 far chain (round 5: one transcendental, 1 / (1 + e) as the series to e^4 for e = eps / |r|^3 < 6e-4) on the bench cloud in
+    float64: the slabs of three patches with the box tables (most (wavefront, patch) rows far) equal the table-less launch (every
+    pair through the exact chain) to 1e-14 of |dE| row by row, and both are within 1e-13 of the fp64 C oracle; the interaction rows
+    agree to 1e-13."""
+    from tools.workloads import headline_workload
+    pc, patches, _ = headline_workload()
+    sizes = np.array([len(p) for p in patches])
+    swork = pc[torch.cat(patches)].double().to(dev)
+    N, P = swork.shape[0], len(patches)
+    off = t(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)).to(dev)
+    sorted_patch = torch.repeat_interleave(torch.arange(P, device=dev), t(sizes).to(dev))
+    boxes, tiles = fu._patch_boxes(swork, off, None), fu._TileTables(swork, sizes)
+    assert boxes.dtype == torch.float64 and tiles.fused
+    for lo in (0, 100, 253):
+        far, W = fu._slabs_and_rows(swork, off, sorted_patch, lo, lo + 3, 1e-5, boxes, tiles, sizes)
+        exact = fu._patch_slabs(swork, off, None, sorted_patch, lo, lo + 3, 1e-5)          # no tables: the exact chain everywhere
+        scale = exact.norm(dim=-1).clamp(min=1e-300)
+        assert float(((far - exact).norm(dim=-1) / scale).max()) < 1e-14
+        W3 = fu._interaction_rows(exact, swork, off, None)
+        assert float((W - W3).abs().max()) <= 1e-13 * float(W3.abs().max())
+        a, b = int(off[lo + 1]), int(off[lo + 2])
+        rows = np.concatenate([np.arange(0, a, 97), np.arange(b, N, 97)])
+        ref = c_oracle.field_grad_f64(swork[a:b].cpu().numpy(), swork.cpu().numpy()[rows])
+        assert rel_rowwise(far[1].cpu().numpy()[rows], ref) < 1e-13
 
 
 # ---- the drivers against the reference's float64 runs (G21) ------------------------------------------------------------
