@@ -421,7 +421,7 @@ static int run_pairs_body(const F* src, int64_t S, int64_t ld_src, const int64_t
         // measured the boxes from two pre-kernels instead - a chunk table and a target-tile table as in patch mode:
         // 4452.6 against 4448.3 us at 100 000^2 on the patch-sorted cloud, no gain: with 780-source chunks the scan is
         // already amortised and the two extra launches cost what the tables save; profiles/r03_k1_tables_ab.txt.)
-        pa.far_d2 = ((double)S * (double)T >= DNP_K1_FAR_FROM) ? (F)far_threshold_d2((double)eps) : F(0);
+        pa.far_d2 = ((double)S * (double)T >= DNP_K1_FAR_FROM) ? (F)far_threshold_d2((double)eps, sizeof(F) == 8 ? kFarRatio64 : kFarRatio) : F(0);
         for (int i = 0; i <= n_chunks; ++i) pa.chunk_off[i] = r.chunk_off[i];
 #ifdef DNP_BOUNDS
         pa.bnd = PairBounds{};
@@ -442,6 +442,10 @@ static int run_pairs_body(const F* src, int64_t S, int64_t ld_src, const int64_t
                                grid, dim3(kBlock), 0, stream, pa);                                                \
         else if (sizeof(F) == 4 && DNP_K1_FAR && pa.far_d2 > F(0))                                                \
             hipLaunchKernelGGL((pair_kernel_scalar<F, double, MODE, KT, V, (sizeof(F) == 4 && DNP_K1_FAR)>), grid, \
+                               dim3(kBlock), 0, stream, pa);                                                      \
+        else if (sizeof(F) == 8 && DNP_K1_FAR && pa.far_d2 > F(0) && KT == kKTScalar && V == kFast && MODE == kField) \
+            /* fp64 (round 5): the one-tier far chain, chunk boxes scanned by the workgroup, no source split */     \
+            hipLaunchKernelGGL((pair_kernel_scalar<F, double, kField, kKTScalar, kFast, (sizeof(F) == 8 && DNP_K1_FAR)>), grid, \
                                dim3(kBlock), 0, stream, pa);                                                      \
         else                                                                                                      \
             hipLaunchKernelGGL((pair_kernel_scalar<F, double, MODE, KT, V, false>), grid, dim3(kBlock), 0, stream, \

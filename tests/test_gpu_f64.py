@@ -49,16 +49,18 @@ def test_f64_field_and_potential_against_the_c_oracle_at_1e13(dev, S, T):
     assert np.all(phi0[:n] == 0) and np.all(np.isfinite(phi0))
 
 
-def test_f64_scalar_kernel_rows_on_the_sorted_sphere(dev):
-    """>= 5e8 pairs: the scalar-unit kernel (KT = 2) and the leaf recursion, 30 000^2 on the patch-sorted sphere - 512 sampled
-    rows against the C oracle at 5e-13 (measured 1.6e-13: rows of 30 000 terms up to 1e7 each, summed in another order than the
+@pytest.mark.parametrize("n", [30000, 34000])
+def test_f64_scalar_kernel_rows_on_the_sorted_sphere(dev, n):
+    """>= 5e8 pairs: the scalar-unit kernel (KT = 2) and the leaf recursion on the patch-sorted sphere - 30 000^2 (the exact chain) and
+    34 000^2 (>= 1e9 pairs: the fp64 far chain of the generic entry points, chunk boxes scanned by the workgroup) - 512 sampled rows
+    against the C oracle at 5e-13 (measured 1.6e-13: rows of 30 000 terms up to 1e7 each, summed in another order than the
     oracle's - the contract is 1e-12), and the fp32 kernel beside it (1e-5)."""
     from tools.workloads import headline_workload
     pc, patches, _ = headline_workload()
     idx = torch.cat([p for p in patches])
-    pts = pc[idx][:30000].double()
+    pts = pc[idx][:n].double()
     E = fu.field_grad(pts.to(dev), pts.to(dev)).cpu().numpy()
-    rows = np.random.default_rng(5).choice(30000, 512, replace=False)
+    rows = np.random.default_rng(5).choice(n, 512, replace=False)
     ref = c_oracle.field_grad_f64(pts.numpy(), pts.numpy()[rows])
     assert rel_rowwise(E[rows], ref) < 5e-13
     E32 = fu.field_grad(pts.float().to(dev), pts.float().to(dev)).cpu().numpy()
