@@ -96,9 +96,23 @@ constexpr size_t kSlabTarget = (size_t)320 << 20;
 #define DNP_K1_SPLIT_CHUNK 1536
 #endif
 constexpr int64_t kSplitChunkSources = DNP_K1_SPLIT_CHUNK;
+#ifndef DNP_K1_SPLIT_CHUNK_SHORT
+#define DNP_K1_SPLIT_CHUNK_SHORT 768
+#endif
+#ifndef DNP_K1_SPLIT_FILL
+#define DNP_K1_SPLIT_FILL 8192
+#endif
+constexpr int64_t kSplitChunkShort = DNP_K1_SPLIT_CHUNK_SHORT, kSplitFillBlocks = DNP_K1_SPLIT_FILL;
 static int64_t choose_chunks(int64_t S, int64_t T, int64_t t_tiles, int64_t n_leaves, int nc, bool scalar_kernel, int split = 1) {
     if (scalar_kernel && split > 1) {
         int64_t want = ceil_div(S, kSplitChunkSources);
+        // few target tiles (the representatives driver's final field: 93 411 sources x 6589 targets = 52 tiles): chunks down to
+        // kSplitChunkShort sources while the launch stays below kSplitFillBlocks workgroups (profiles/r05_rest_field_ab.txt)
+        if (t_tiles * want < kSplitFillBlocks) {
+            int64_t fill = kSplitFillBlocks / t_tiles;
+            if (fill > ceil_div(S, kSplitChunkShort)) fill = ceil_div(S, kSplitChunkShort);
+            if (want < fill) want = fill;
+        }
         const int64_t slab = (int64_t)(kSlabTarget / ((size_t)(T > 0 ? T : 1) * nc * sizeof(double)));
         if (want > slab) want = slab;
         return want < n_leaves ? n_leaves : want;
@@ -385,10 +399,15 @@ static int run_pairs_body(const F* src, int64_t S, int64_t ld_src, const int64_t
 #ifndef DNP_K1_FAR_FROM
 #define DNP_K1_FAR_FROM 1e9
 #endif
+#ifndef DNP_K1_FAR_FROM_WIDE  // ... and from here already when there are at least twice as many sources as targets (round 5: the
+#define DNP_K1_FAR_FROM_WIDE 5e8   // representatives driver's final field 93 411 x 6589: 397 -> 371 us, 100 000 x 8000: 496 -> 458 us,
+#endif                        // 50 000 x 12 000: 365 -> 350 us; 30 000^2 on an unsorted cloud would lose 1.5 % - profiles/r05_rest_field_ab.txt)
     const bool scalar_kernel = (src_idx == nullptr) && !DNP_K1_FORCE_LDS && (double)S * (double)T >= DNP_K1_SCALAR_FROM;
     // far-field launches (fp32, >= 10^9 pairs, eps in range) of the scalar kernel split their work items by source
+    const double n_pairs = (double)S * (double)T;
+    const bool far_size = n_pairs >= DNP_K1_FAR_FROM || (n_pairs >= DNP_K1_FAR_FROM_WIDE && S >= 2 * T);
     const bool far_candidate = sizeof(F) == 4 && DNP_K1_FAR && scalar_kernel && MODE == kField && eps > F(0) &&
-                               (double)S * (double)T >= DNP_K1_FAR_FROM && far_threshold_d2((double)eps) > 0.0;
+                               far_size && far_threshold_d2((double)eps) > 0.0;
     const int split = (far_candidate && T >= (int64_t)kBlock * kKTScalar * kTilesForLarge) ? DNP_K1_SPLIT : 1;
     const Plan plan = make_plan(S, T, max_pts, NC, sizeof(double), scalar_kernel, split);
     const size_t need = plan_workspace(plan, T, NC, sizeof(double));
@@ -421,7 +440,7 @@ static int run_pairs_body(const F* src, int64_t S, int64_t ld_src, const int64_t
         // measured the boxes from two pre-kernels instead - a chunk table and a target-tile table as in patch mode:
         // 4452.6 against 4448.3 us at 100 000^2 on the patch-sorted cloud, no gain: with 780-source chunks the scan is
         // already amortised and the two extra launches cost what the tables save; profiles/r03_k1_tables_ab.txt.)
-        pa.far_d2 = ((double)S * (double)T >= DNP_K1_FAR_FROM) ? (F)far_threshold_d2((double)eps, sizeof(F) == 8 ? kFarRatio64 : kFarRatio) : F(0);
+        pa.far_d2 = (sizeof(F) == 8 ? n_pairs >= DNP_K1_FAR_FROM : far_size) ? (F)far_threshold_d2((double)eps, sizeof(F) == 8 ? kFarRatio64 : kFarRatio) : F(0);
         for (int i = 0; i <= n_chunks; ++i) pa.chunk_off[i] = r.chunk_off[i];
 #ifdef DNP_BOUNDS
         pa.bnd = PairBounds{};

@@ -963,8 +963,7 @@ def strongest_field_propagation_reps(input_pc, reps, diffuse=False, weights=None
             # the pair kernel here - profiles/r05_config3_kernels.txt).  The loop's targets are representatives only: the
             # sorted cloud of the propagation is built straight from `work` through the representatives' index list
             # (subset), the fused tail stores their oriented normals back into `work`, the field of ALL representatives
-            # (sources in point order, as the reference sums them: field_grad(pts[oriented_pts_mask], ...)) is evaluated at
-            # the rest points, and one launch gives every rest point its patch's flip and the sign of that field.
+            # is evaluated at the rest points, and one launch gives every rest point its patch's flip and the sign of that field.
             lib = _lib.require_device()
             f64 = work.dtype == torch.float64
             st = _batched_patch_propagation(work, rep_lists, start_t, diffuse, subset=True)
@@ -977,8 +976,11 @@ def strongest_field_propagation_reps(input_pc, reps, diffuse=False, weights=None
             _lib.check(rc)
             if n_rest:
                 rest = rest_csr[1]                                # targets are independent rows: their order is free
-                # sources as a compact copy in point order: contiguous rows go through the scalar-unit kernel
-                src = work[reps.sorted_reps(dev)].contiguous()
+                # sources as a compact copy in PATCH order: contiguous rows go through the scalar-unit kernel and chunks of one or
+                # two patches have tight boxes, so the far-field chain fires (the reference sums them in point order,
+                # field_grad(pts[oriented_pts_mask], ...): the same sum up to fp32 rounding - the kernels add fp64 chunk sums - and
+                # up to which 15 000-source leaf an Inf / NaN pair would blank; 392 -> 359 us, profiles/r05_rest_field_ab.txt)
+                src = work[all_reps].contiguous()
                 E2 = torch.empty((n_rest, 3), dtype=work.dtype, device=dev)
                 _pairs_into("field", src, None, work, rest, 1e-5, 15000, E2)
                 with _on_device(dev):

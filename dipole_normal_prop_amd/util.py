@@ -223,15 +223,7 @@ class RepLists(list):
 
     def __init__(self, reps: PatchList, rests: PatchList):
         self.reps, self.rests = reps, rests
-        self._sorted_reps = None
         super().__init__(zip(reps, rests))
-
-    def sorted_reps(self, dev) -> torch.Tensor:
-        """All representatives in point order (the order in which the reference's final field_grad sums them),
-        sorted once per object and device."""
-        if self._sorted_reps is None or self._sorted_reps.device != torch.device(dev):
-            self._sorted_reps = torch.sort(self.reps.flat.to(device=dev, dtype=torch.int64)).values
-        return self._sorted_reps
 
 
 def patch_csr(patches, dev):
@@ -239,6 +231,10 @@ def patch_csr(patches, dev):
     if isinstance(patches, PatchList) and len(patches) == len(patches.sizes):
         sizes = np.asarray(patches.sizes, dtype=np.int64)
         idx = patches.flat.to(device=dev, dtype=torch.int64)
+        cached = getattr(patches, "_off", None)           # the offsets travel to a device once per object (sizes are fixed at construction)
+        if cached is None or cached.device != torch.device(dev) or cached.shape[0] != len(sizes) + 1:
+            cached = patches._off = to_device(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64), dev)
+        return cached, idx, sizes
     else:
         sizes = np.array([int(p.shape[0]) for p in patches], dtype=np.int64)
         idx = torch.cat([p.to(device=dev, dtype=torch.int64) for p in patches]) if len(patches) else \
