@@ -1,5 +1,6 @@
 // dnp_xie.hip - the fork's "xie" pair functions:
 //   xie_field / xie_intersaction  (field_utils.py:431-469, :509-519)  -> dnp_xie_pairs_f32/_f64
+//   their knn_mask > 0 branch (field_utils.py:451-460, 467-468)        -> dnp_xie_knn_f32/_f64 + dnp_xie_pairs_knn_f32/_f64
 //   xie_propagation_points_in_order (field_utils.py:569-605)           -> dnp_xie_order_f32/_f64, its diffuse pass (:597-603)
 //                                                                          -> dnp_xie_rowdots_f32/_f64
 //
@@ -34,7 +35,18 @@ struct XieArgs {
     F C;
     int vector_out;
     F* out;
+    const double* kth_d2;     // KNN form: per source, squared distance and index of its k-th nearest target (xie_knn_kernel)
+    const int64_t* kth_idx;
 };
+
+// squared distance of the kNN mask: fp64 on the exact coordinates, as the reference's KDTree sees them (field_utils.py:453-458:
+// the tree is built on the numpy view of the cloud and computes in double).  ONE function for the selection and for the mask
+// test of the pair kernel: both must see the same bits (the file compiles with fp contraction off).
+template <typename F>
+__device__ __forceinline__ double knn_d2(F sx, F sy, F sz, F tx, F ty, F tz) {
+    const double dx = (double)sx - (double)tx, dy = (double)sy - (double)ty, dz = (double)sz - (double)tz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
 
 // correctly rounded square root in the operand's own precision (__builtin_sqrt on a float is the DOUBLE root: v_rsq_f64 and
 // eight fp64 fmas per pair until round 3 - the same bits, since a double root rounded to float is the correctly rounded
@@ -78,7 +90,7 @@ struct Recip {
     }
 };
 
-template <typename F, bool VEC>
+template <typename F, bool VEC, bool KNN = false>
 __global__ __launch_bounds__(kXieBlock) void xie_pairs_kernel(const XieArgs<F> a) {
     __shared__ __attribute__((aligned(16))) F tl[kXieTargets][8];       // rows of 8: one wide LDS read per half row
     const int tid = threadIdx.x;
@@ -93,6 +105,9 @@ __global__ __launch_bounds__(kXieBlock) void xie_pairs_kernel(const XieArgs<F> a
     if (s >= a.S) return;
     const F* ps = a.src + s * a.ld_src;
     const F sx = ps[0], sy = ps[1], sz = ps[2], nx = ps[3], ny = ps[4], nz = ps[5];
+    double kd = 0.0;
+    int64_t ki = 0;
+    if constexpr (KNN) { kd = a.kth_d2[s]; ki = a.kth_idx[s]; }
     F* po = a.out + (t0 * a.S + s) * (VEC ? 3 : 1);                  // one 64-bit address, then a constant stride per target
     const int64_t step = a.S * (VEC ? 3 : 1);
     for (int r = 0; r < nt; ++r, po += step) {
@@ -117,6 +132,13 @@ __global__ __launch_bounds__(kXieBlock) void xie_pairs_kernel(const XieArgs<F> a
             fy = coincident ? ny : by_n3.divide(ny - d * uy);
             fz = coincident ? nz : by_n3.divide(nz - d * uz);
         }
+        if constexpr (KNN) {
+            // `ref_normal_s *= tree_mask[:, :, None]` (field_utils.py:467-468): target t0 + r is among the k nearest targets of
+            // this source iff (d2, index) <= the k-th pair; the others are multiplied by 0 (an Inf / NaN entry turns NaN, as there)
+            const double d2 = knn_d2<F>(sx, sy, sz, tl[r][0], tl[r][1], tl[r][2]);
+            const bool in = d2 < kd || (d2 == kd && t0 + r <= ki);
+            if (!in) { fx = fx * F(0); fy = fy * F(0); fz = fz * F(0); }
+        }
         if constexpr (VEC) {
             po[0] = fx; po[1] = fy; po[2] = fz;
         } else {
@@ -125,6 +147,96 @@ __global__ __launch_bounds__(kXieBlock) void xie_pairs_kernel(const XieArgs<F> a
             po[0] = v;
         }
     }
+}
+
+// ---- kNN selection for the masked forms (field_utils.py:451-460: KDTree(targets).query(sources, k)) ----------------------
+// One wavefront per source; the wave keeps the 64 smallest (d2, index) pairs seen so far SORTED ACROSS ITS LANES (lane i = the
+// (i+1)-th smallest), and the value in lane m-1 (m = min(k, 64)) is the bar a candidate has to beat.  Targets are staged
+// through LDS in tiles shared by the workgroup's four sources; every lane computes one distance per iteration, a ballot names
+// the lanes under the bar (after the first few hundred targets: rarely any - about k ln(T / k) insertions per source in all)
+// and the wave inserts those one at a time: the lanes behind the insertion point take their left neighbour's pair (DPP
+// wave_shr:1, register to register).  Everything about an insertion is wave-uniform, so no lane idles through another lane's
+// work.  (The first form of this kernel kept a sorted list per LANE: nearly every iteration had some lane inserting, and the
+// whole wave walked its compare-and-shift chain - 807 us at N = 10 000, k = 20 against this form's figure in
+// profiles/r05_xie_time.txt.)  k > 64: further passes, each restricted to pairs behind the last one taken.  The result is the
+// k-th pair per source; ties at equal distance go to the lower target index (the tree's choice among equidistant targets is an
+// implementation detail; fp64 distances of distinct points rarely tie).
+constexpr int kKnnBlock = 256, kKnnTile = 1024;
+
+// lane i takes lane i-1's value, lane 0 takes `first` (DPP wave_shr:1 - gfx9 only, like the row_bcast folds of wave_sum_f64)
+__device__ __forceinline__ int wave_shr1_i32(int v, int first) {
+    return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ double wave_shr1_f64(double v, double first) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v), f = __builtin_bit_cast(unsigned long long, first);
+    const unsigned lo = (unsigned)wave_shr1_i32((int)(unsigned)(b & 0xffffffffull), (int)(unsigned)(f & 0xffffffffull));
+    const unsigned hi = (unsigned)wave_shr1_i32((int)(unsigned)(b >> 32), (int)(unsigned)(f >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffull), l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+template <typename F>
+__global__ __launch_bounds__(kKnnBlock) void xie_knn_kernel(const F* __restrict__ src, int64_t S, int64_t ld_src,
+                                                            const F* __restrict__ tgt, int64_t T, int64_t ld_tgt, int k,
+                                                            double* __restrict__ kth_d2, int64_t* __restrict__ kth_idx) {
+    __shared__ F tl[3][kKnnTile];                                     // coordinate-major: lane l reads tl[c][j + l], no conflicts
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t s = (int64_t)blockIdx.x * (kKnnBlock / 64) + wave;
+    const bool live = s < S;                                           // dead waves keep the barriers company
+    F sx = F(0), sy = F(0), sz = F(0);
+    if (live) { sx = src[s * ld_src]; sy = src[s * ld_src + 1]; sz = src[s * ld_src + 2]; }
+    double prev_d = -1.0;                                              // every pair is behind (-1, -1): d2 >= 0
+    int prev_i = -1;
+    for (int remaining = k; remaining > 0;) {                          // the same count in every wave of the workgroup
+        const int m = remaining < 64 ? remaining : 64;
+        double ld = __builtin_huge_val();                              // the wave's sorted list, one pair per lane
+        int li = 0x7fffffff;
+        double bar = __builtin_huge_val();                             // lane m-1's distance (wave-uniform)
+        for (int64_t t0 = 0; t0 < T; t0 += kKnnTile) {
+            const int nt = (int)((T - t0) < kKnnTile ? (T - t0) : kKnnTile);
+            __syncthreads();                                           // the previous tile has been consumed
+            for (int i = threadIdx.x; i < nt * 3; i += kKnnBlock) {
+                const int r = i / 3, c = i - r * 3;
+                tl[c][r] = tgt[(t0 + r) * ld_tgt + c];
+            }
+            __syncthreads();
+            if (!live) continue;
+            for (int j0 = 0; j0 < nt; j0 += 64) {
+                const int j = j0 + lane;
+                double d = __builtin_huge_val();
+                if (j < nt) d = knn_d2<F>(sx, sy, sz, tl[0][j], tl[1][j], tl[2][j]);
+                const int t = (int)(t0 + j);
+                const bool behind = d > prev_d || (d == prev_d && t > prev_i);
+                // strict: targets arrive in index order, so an equal distance with a (necessarily higher) index stays out
+                unsigned long long todo = __ballot(behind && d < bar);
+                while (todo) {
+                    const int l = (int)__builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const double cd = readlane_f64(d, l);
+                    if (!(cd < bar)) continue;                         // the bar has come down since the ballot
+                    const int ci = (int)(t0 + j0) + l;
+                    const bool gt = ld > cd;                           // a suffix of the lanes (the list is sorted)
+                    const double sd = wave_shr1_f64(ld, -1.0);         // lane 0 has no left neighbour: -1 is never > cd
+                    const int si = wave_shr1_i32(li, -1);
+                    const bool first = !(sd > cd);                     // ... the first lane of the suffix takes the candidate
+                    li = gt ? (first ? ci : si) : li;
+                    ld = gt ? (first ? cd : sd) : ld;
+                    bar = readlane_f64(ld, m - 1);
+                }
+            }
+        }
+        if (live) {
+            prev_d = bar;
+            prev_i = __builtin_amdgcn_readlane(li, m - 1);
+        }
+        remaining -= m;
+    }
+    if (live && lane == 0) { kth_d2[s] = prev_d; kth_idx[s] = prev_i; }
 }
 
 constexpr int kOrderThreads = 1024;
@@ -334,7 +446,8 @@ __global__ __launch_bounds__(256) void xie_rowdots_kernel(const F* __restrict__ 
 
 template <typename F>
 static int run_xie_pairs(const F* src, int64_t S, int64_t ld_src, const F* tgt, int64_t T, int64_t ld_tgt, F C,
-                         int vector_out, F* out, hipStream_t stream) {
+                         int vector_out, F* out, hipStream_t stream, const double* kth_d2 = nullptr,
+                         const int64_t* kth_idx = nullptr) {
     clear_error();
     DNP_REQUIRE(S >= 0 && T >= 0, "negative size");
     if (S == 0 || T == 0) return DNP_OK;
@@ -342,10 +455,32 @@ static int run_xie_pairs(const F* src, int64_t S, int64_t ld_src, const F* tgt, 
     DNP_REQUIRE(ld_src >= 6 && ld_tgt >= 6, "xie pairs need 6-column sources and targets");
     const int64_t gy = ceil_div(T, (int64_t)kXieTargets);
     DNP_REQUIRE(gy <= 65535, "T=%lld exceeds %d targets per launch", (long long)T, 65535 * kXieTargets);
-    XieArgs<F> a{src, S, ld_src, tgt, T, ld_tgt, C, vector_out, out};
+    DNP_REQUIRE((kth_d2 == nullptr) == (kth_idx == nullptr), "kth_d2 and kth_idx come together");
+    XieArgs<F> a{src, S, ld_src, tgt, T, ld_tgt, C, vector_out, out, kth_d2, kth_idx};
     const dim3 grid((unsigned)ceil_div(S, (int64_t)kXieBlock), (unsigned)gy);
-    if (vector_out) hipLaunchKernelGGL((xie_pairs_kernel<F, true>), grid, dim3(kXieBlock), 0, stream, a);
-    else hipLaunchKernelGGL((xie_pairs_kernel<F, false>), grid, dim3(kXieBlock), 0, stream, a);
+    if (kth_d2) {
+        if (vector_out) hipLaunchKernelGGL((xie_pairs_kernel<F, true, true>), grid, dim3(kXieBlock), 0, stream, a);
+        else hipLaunchKernelGGL((xie_pairs_kernel<F, false, true>), grid, dim3(kXieBlock), 0, stream, a);
+    } else {
+        if (vector_out) hipLaunchKernelGGL((xie_pairs_kernel<F, true>), grid, dim3(kXieBlock), 0, stream, a);
+        else hipLaunchKernelGGL((xie_pairs_kernel<F, false>), grid, dim3(kXieBlock), 0, stream, a);
+    }
+    DNP_CHECK_HIP(hipGetLastError());
+    return DNP_OK;
+}
+
+template <typename F>
+static int run_xie_knn(const F* src, int64_t S, int64_t ld_src, const F* tgt, int64_t T, int64_t ld_tgt, int64_t k,
+                       double* kth_d2, int64_t* kth_idx, hipStream_t stream) {
+    clear_error();
+    DNP_REQUIRE(S >= 0 && T >= 0, "negative size");
+    DNP_REQUIRE(k >= 1 && k <= T, "k=%lld outside 1..T=%lld (the caller clamps: min(len(targets), knn_mask))", (long long)k, (long long)T);
+    if (S == 0) return DNP_OK;
+    DNP_REQUIRE(src && tgt && kth_d2 && kth_idx, "NULL pointer");
+    DNP_REQUIRE(ld_src >= 3 && ld_tgt >= 3, "kNN needs 3 coordinate columns");
+    DNP_REQUIRE(T <= INT32_MAX, "T=%lld exceeds 2^31-1 targets", (long long)T);
+    const dim3 grid((unsigned)ceil_div(S, (int64_t)(kKnnBlock / 64)));
+    hipLaunchKernelGGL((xie_knn_kernel<F>), grid, dim3(kKnnBlock), 0, stream, src, S, ld_src, tgt, T, ld_tgt, (int)k, kth_d2, kth_idx);
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
 }
@@ -414,6 +549,30 @@ int dnp_xie_pairs_f32(const float* src, int64_t S, int64_t ld_src, const float* 
 int dnp_xie_pairs_f64(const double* src, int64_t S, int64_t ld_src, const double* tgt, int64_t T, int64_t ld_tgt,
                       double C, int vector_out, double* out, void* stream) {
     return run_xie_pairs<double>(src, S, ld_src, tgt, T, ld_tgt, C, vector_out, out, (hipStream_t)stream);
+}
+
+int dnp_xie_knn_f32(const float* src, int64_t S, int64_t ld_src, const float* tgt, int64_t T, int64_t ld_tgt, int64_t k,
+                    double* kth_d2, int64_t* kth_idx, void* stream) {
+    return run_xie_knn<float>(src, S, ld_src, tgt, T, ld_tgt, k, kth_d2, kth_idx, (hipStream_t)stream);
+}
+
+int dnp_xie_knn_f64(const double* src, int64_t S, int64_t ld_src, const double* tgt, int64_t T, int64_t ld_tgt, int64_t k,
+                    double* kth_d2, int64_t* kth_idx, void* stream) {
+    return run_xie_knn<double>(src, S, ld_src, tgt, T, ld_tgt, k, kth_d2, kth_idx, (hipStream_t)stream);
+}
+
+int dnp_xie_pairs_knn_f32(const float* src, int64_t S, int64_t ld_src, const float* tgt, int64_t T, int64_t ld_tgt,
+                          float C, int vector_out, const double* kth_d2, const int64_t* kth_idx, float* out, void* stream) {
+    clear_error();
+    DNP_REQUIRE(kth_d2 && kth_idx, "NULL kNN thresholds");
+    return run_xie_pairs<float>(src, S, ld_src, tgt, T, ld_tgt, C, vector_out, out, (hipStream_t)stream, kth_d2, kth_idx);
+}
+
+int dnp_xie_pairs_knn_f64(const double* src, int64_t S, int64_t ld_src, const double* tgt, int64_t T, int64_t ld_tgt,
+                          double C, int vector_out, const double* kth_d2, const int64_t* kth_idx, double* out, void* stream) {
+    clear_error();
+    DNP_REQUIRE(kth_d2 && kth_idx, "NULL kNN thresholds");
+    return run_xie_pairs<double>(src, S, ld_src, tgt, T, ld_tgt, C, vector_out, out, (hipStream_t)stream, kth_d2, kth_idx);
 }
 
 int dnp_xie_order_f32(const float* M, int64_t N, const int64_t* order, int64_t R, float* weights, float* inter,

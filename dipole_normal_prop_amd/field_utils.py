@@ -49,7 +49,7 @@ SLAB_FREE_CHECK_BYTES = 1 << 30
 
 from ._staging import (_NULL, _WS_BYTES, _compute_device, _idx, _ld, _on_device, _pairs_into, _set_trace, _stage, _tls,  # noqa: F401
                        _warn_state, _work_dtype, _workspace, flush_warnings, last_trace)
-from .xie import (_xie_knn_mask, _xie_pairs, align_votes, xie_distance, xie_field, xie_intersaction,  # noqa: F401
+from .xie import (_xie_pairs, align_votes, xie_distance, xie_field, xie_intersaction,  # noqa: F401
                   xie_propagation_points_in_order, xie_propagation_points_onbfstree)
 
 

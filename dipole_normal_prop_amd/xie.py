@@ -1,7 +1,8 @@
 """The fork's "xie" pair functions of the reference's field_utils: xie_field / xie_intersaction / xie_distance
 (field_utils.py:431-526), the ordered sign propagation xie_propagation_points_in_order (:569-605) and the BFS-route propagation
 with its vote, xie_propagation_points_onbfstree (:657-710) - same names, argument order and defaults; the pair matrix, the ordered
-loop and its diffuse pass run in csrc/dnp_xie.hip behind the C ABI (dnp_xie_pairs_*, dnp_xie_order_*, dnp_xie_rowdots_*), in the
+loop, its diffuse pass and the kNN mask run in csrc/dnp_xie.hip behind the C ABI (dnp_xie_pairs_*, dnp_xie_knn_*, dnp_xie_pairs_knn_*,
+dnp_xie_order_*, dnp_xie_rowdots_*), in the
 cloud's own precision (float64 clouds in float64).  Split out of field_utils.py in round 5; every public name is re-exported there."""
 import numpy as np
 import torch
@@ -11,7 +12,10 @@ from . import util
 from ._staging import _compute_device, _ld, _on_device, _set_trace, _stage, _work_dtype
 
 
-def _xie_pairs(source, target, C, vector_out):
+def _xie_pairs(source, target, C, vector_out, knn_mask=-1):
+    """dnp_xie_pairs on staged tensors; knn_mask > 0: dnp_xie_knn (the k-th nearest target of every source, fp64 distances on
+    the exact coordinates as the reference's KDTree computes them, field_utils.py:451-460) and dnp_xie_pairs_knn (entries
+    outside the k nearest multiplied by 0, :467-468) - no T x S mask tensor."""
     lib = _lib.require_device()
     if source.dim() != 2 or source.shape[1] < 6 or target.dim() != 2 or target.shape[1] < 6:
         raise ValueError("xie pair functions need [S,6] sources and [T,6] targets")
@@ -23,28 +27,24 @@ def _xie_pairs(source, target, C, vector_out):
     S, T = src.shape[0], tgt.shape[0]
     out = torch.empty((T, S, 3) if vector_out else (T, S), dtype=wd, device=dev)
     if S and T:
-        fn = lib.dnp_xie_pairs_f64 if wd == torch.float64 else lib.dnp_xie_pairs_f32
+        f64 = wd == torch.float64
         with _on_device(dev):
-            rc = fn(_lib.ptr(src), S, _ld(src), _lib.ptr(tgt), T, _ld(tgt), float(C), int(vector_out), _lib.ptr(out),
+            if knn_mask > 0:
+                k = min(T, int(knn_mask))                                  # k = min(len(xyz), knn_mask), :456
+                kth_d2 = torch.empty(S, dtype=torch.float64, device=dev)
+                kth_idx = torch.empty(S, dtype=torch.int64, device=dev)
+                _lib.check((lib.dnp_xie_knn_f64 if f64 else lib.dnp_xie_knn_f32)(
+                    _lib.ptr(src), S, _ld(src), _lib.ptr(tgt), T, _ld(tgt), k, _lib.ptr(kth_d2), _lib.ptr(kth_idx),
+                    _lib.current_stream()))
+                rc = (lib.dnp_xie_pairs_knn_f64 if f64 else lib.dnp_xie_pairs_knn_f32)(
+                    _lib.ptr(src), S, _ld(src), _lib.ptr(tgt), T, _ld(tgt), float(C), int(vector_out), _lib.ptr(kth_d2),
+                    _lib.ptr(kth_idx), _lib.ptr(out), _lib.current_stream())
+            else:
+                rc = (lib.dnp_xie_pairs_f64 if f64 else lib.dnp_xie_pairs_f32)(
+                    _lib.ptr(src), S, _ld(src), _lib.ptr(tgt), T, _ld(tgt), float(C), int(vector_out), _lib.ptr(out),
                     _lib.current_stream())
         _lib.check(rc)
     return out.to(device=in_dev, dtype=in_dtype) if (out.device != in_dev or out.dtype != in_dtype) else out
-
-
-def _xie_knn_mask(source, target, k):
-    """[T,S] 0/1 mask: 1 where target t is among the k nearest targets of source s (the reference builds a
-    scipy KDTree on the targets and queries it with the sources, field_utils.py:451-460); brute force on the
-    tensors' device, distances in fp64."""
-    k = min(int(target.shape[0]), int(k))
-    sx, tx = source[:, :3].double(), target[:, :3].double()
-    mask = torch.zeros((target.shape[0], source.shape[0]), dtype=torch.float64, device=source.device)
-    step = max(1, (1 << 24) // max(int(target.shape[0]), 1))
-    for s0 in range(0, source.shape[0], step):
-        d2 = ((sx[s0:s0 + step, None, :] - tx[None, :, :]) ** 2).sum(dim=-1)          # [s, T]
-        nn = d2.topk(k, dim=1, largest=False).indices                                # [s, k]
-        cols = torch.arange(s0, s0 + nn.shape[0], device=source.device)[:, None].expand_as(nn)
-        mask[nn.reshape(-1), cols.reshape(-1)] = 1.0
-    return mask
 
 
 def xie_field(source: torch.Tensor, target: torch.Tensor, eps, max_pts=5000, knn_mask=-1, C=3):
@@ -53,21 +53,13 @@ def xie_field(source: torch.Tensor, target: torch.Tensor, eps, max_pts=5000, knn
     each source.  `eps` and `max_pts` are accepted and unused (the reference ignores eps; its recursion above
     max_pts**2 pairs only bounds temporaries - and drops C / knn_mask on the way, which this does not)."""
     with torch.no_grad():
-        out = _xie_pairs(source, target, C, True)
-        if knn_mask > 0:
-            out = out * _xie_knn_mask(source, target, knn_mask).to(out.device)[:, :, None]
-        return out
+        return _xie_pairs(source, target, C, True, knn_mask)
 
 
 def xie_intersaction(source: torch.Tensor, target: torch.Tensor, eps, knn_mask, C):
     """[T,S] interaction matrix xie_field . n_t with NaN/Inf zeroed (field_utils.py:509-519)."""
     with torch.no_grad():
-        if knn_mask > 0:
-            out = (xie_field(source, target, eps, knn_mask=knn_mask, C=C) * target[:, None, 3:]).sum(dim=-1)
-            out[out.isnan()] = 0
-            out[out.isinf()] = 0
-            return out
-        return _xie_pairs(source, target, C, False)
+        return _xie_pairs(source, target, C, False, knn_mask)
 
 
 def xie_distance(source: torch.Tensor, target: torch.Tensor, eps):

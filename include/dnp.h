@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DNP_VERSION 500 /* 0.5.0: the fp64 patch-driver entry points, dnp_xie_order_f64, dnp_xie_rowdots_* */
+#define DNP_VERSION 501 /* 0.5.1: + dnp_xie_knn_*, dnp_xie_pairs_knn_* (0.5.0: the fp64 patch-driver entry points, dnp_xie_order_f64, dnp_xie_rowdots_*) */
 
 enum {
     DNP_OK = 0,
@@ -396,6 +396,12 @@ int dnp_merge_cells(const int32_t* cell_ijk, const int64_t* cell_size, int64_t C
  * there).  vector_out != 0: out is [T, S, 3] = ref;  vector_out == 0: out is [T, S] = ref . n_t with NaN/Inf
  * zeroed (field_utils.xie_intersaction, field_utils.py:509-519).  Sources and targets are [*, >=6] rows.
  *
+ * dnp_xie_knn + dnp_xie_pairs_knn: the knn_mask > 0 forms (field_utils.py:451-460, 467-468; the reference builds a scipy KDTree
+ * on the targets, queries it with the sources and multiplies ref by the resulting 0/1 mask).  dnp_xie_knn gives, per source, the
+ * squared distance kth_d2[s] (fp64 on the exact coordinates, as the tree computes) and the index kth_idx[s] of its k-th nearest
+ * target, 1 <= k <= T, ties at equal distance to the lower index; dnp_xie_pairs_knn is dnp_xie_pairs with every entry whose
+ * target is not among those k - (d2, t) > (kth_d2[s], kth_idx[s]) - multiplied by 0.  No T x S mask is ever stored.
+ *
  * dnp_xie_order: the ordered propagation loop of field_utils.xie_propagation_points_in_order
  * (field_utils.py:590-595) for R visiting orders over an N x N interaction matrix M (row = receiving point):
  *   for i in 0..N-1:  idx = order[r][i];  inter[r][idx] = sum_j M[idx][j] * w[r][j];
@@ -411,6 +417,14 @@ int dnp_xie_pairs_f32(const float* src, int64_t S, int64_t ld_src, const float* 
                       float C, int vector_out, float* out, void* stream);
 int dnp_xie_pairs_f64(const double* src, int64_t S, int64_t ld_src, const double* tgt, int64_t T, int64_t ld_tgt,
                       double C, int vector_out, double* out, void* stream);
+int dnp_xie_knn_f32(const float* src, int64_t S, int64_t ld_src, const float* tgt, int64_t T, int64_t ld_tgt, int64_t k,
+                    double* kth_d2, int64_t* kth_idx, void* stream);
+int dnp_xie_knn_f64(const double* src, int64_t S, int64_t ld_src, const double* tgt, int64_t T, int64_t ld_tgt, int64_t k,
+                    double* kth_d2, int64_t* kth_idx, void* stream);
+int dnp_xie_pairs_knn_f32(const float* src, int64_t S, int64_t ld_src, const float* tgt, int64_t T, int64_t ld_tgt,
+                          float C, int vector_out, const double* kth_d2, const int64_t* kth_idx, float* out, void* stream);
+int dnp_xie_pairs_knn_f64(const double* src, int64_t S, int64_t ld_src, const double* tgt, int64_t T, int64_t ld_tgt,
+                          double C, int vector_out, const double* kth_d2, const int64_t* kth_idx, double* out, void* stream);
 int dnp_xie_order_f32(const float* M, int64_t N, const int64_t* order, int64_t R, float* weights, float* inter,
                       void* stream);
 int dnp_xie_order_f64(const double* M, int64_t N, const int64_t* order, int64_t R, double* weights, double* inter,

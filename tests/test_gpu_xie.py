@@ -179,3 +179,73 @@ def test_xie_order_kernel_is_its_specification_bit_for_bit(dev, n):
         want_i, want_w = _order_kernel_spec(Mh, orders[r])
         assert np.array_equal(inter[r].cpu().numpy(), want_i)
         assert np.array_equal(weights[r].cpu().numpy(), want_w)
+
+
+def _knn_brute(src, tgt, k):
+    """(kth_d2, kth_idx) per source by (d2, index) order: fp64 on the exact coordinates, (dx^2 + dy^2) + dz^2 as the kernel"""
+    s, q = src[:, :3].double().cpu().numpy(), tgt[:, :3].double().cpu().numpy()
+    d = s[:, None, :] - q[None, :, :]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    idx = np.broadcast_to(np.arange(q.shape[0]), d2.shape)
+    kd, ki = np.empty(s.shape[0]), np.empty(s.shape[0], dtype=np.int64)
+    for i in range(s.shape[0]):
+        o = np.lexsort((idx[i], d2[i]))[k - 1]
+        kd[i], ki[i] = d2[i, o], o
+    return kd, ki, d2
+
+
+def _knn_native(src, tgt, k):
+    import ctypes
+    from dipole_normal_prop_amd import _lib
+    lib = _lib.require_device()
+    S, T = src.shape[0], tgt.shape[0]
+    kd = torch.full((S,), -7.0, dtype=torch.float64, device=src.device)
+    ki = torch.full((S,), -7, dtype=torch.int64, device=src.device)
+    fn = lib.dnp_xie_knn_f64 if src.dtype == torch.float64 else lib.dnp_xie_knn_f32
+    rc = fn(_lib.ptr(src), S, src.stride(0), _lib.ptr(tgt), T, tgt.stride(0), k, _lib.ptr(kd), _lib.ptr(ki),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return rc, kd.cpu().numpy(), ki.cpu().numpy()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_xie_knn_selection_is_the_brute_force_kth_pair(dev, dtype):
+    """dnp_xie_knn (field_utils.py:451-460) against a lexsort of all fp64 distances: the k-th (d2, index) pair of every source, bit
+    for bit - one pass (k <= 64: the list the wave keeps across its lanes), several passes (k = 65, 70, 200), k = T, more targets than one LDS tile,
+    and a source count that is not a multiple of the workgroup's four."""
+    gen = torch.Generator().manual_seed(11)
+    src = torch.rand(203, 6, generator=gen, dtype=torch.float64).to(dtype).to(dev)
+    tgt = torch.rand(2500, 6, generator=gen, dtype=torch.float64).to(dtype).to(dev)
+    for k in (1, 5, 8, 17, 32, 33, 63, 64, 65, 70, 200):
+        rc, kd, ki = _knn_native(src, tgt, k)
+        ed, ei, _ = _knn_brute(src, tgt, k)
+        assert rc == 0 and np.array_equal(ki, ei) and np.array_equal(kd, ed), k
+    small = tgt[:37].contiguous()
+    rc, kd, ki = _knn_native(src, small, 37)                       # k = T: the farthest target
+    ed, ei, _ = _knn_brute(src, small, 37)
+    assert rc == 0 and np.array_equal(ki, ei) and np.array_equal(kd, ed)
+    assert _knn_native(src, small, 38)[0] != 0 and _knn_native(src, small, 0)[0] != 0     # the caller clamps k to 1..T
+
+
+def test_xie_knn_ties_go_to_the_lower_index_and_the_mask_has_k_entries(dev):
+    """Every target listed three times (exact ties, across lanes and inside one lane's list): exactly k mask entries per source,
+    the lower index first; the masked forms are the unmasked ones times that mask, fp32 and fp64, matrix and tensor."""
+    gen = torch.Generator().manual_seed(12)
+    base = torch.rand(150, 6, generator=gen)
+    tgt = torch.cat([base, base, base])[torch.randperm(450, generator=gen)].contiguous().to(dev)
+    src = torch.rand(70, 6, generator=gen).to(dev)
+    for k in (1, 4, 7, 20, 40, 130):
+        rc, kd, ki = _knn_native(src, tgt, k)
+        ed, ei, d2 = _knn_brute(src, tgt, k)
+        assert rc == 0 and np.array_equal(ki, ei) and np.array_equal(kd, ed), k
+        mask = (d2 < ed[:, None]) | ((d2 == ed[:, None]) & (np.arange(450)[None, :] <= ei[:, None]))      # [S, T]
+        assert np.array_equal(mask.sum(axis=1), np.full(70, k))
+        for cast in (torch.float32, torch.float64):
+            s_, t_ = src.to(cast), tgt.to(cast)
+            full = fu.xie_intersaction(s_, t_, 0.1, -1, 3).cpu().numpy()
+            got = fu.xie_intersaction(s_, t_, 0.1, k, 3).cpu().numpy()
+            assert np.array_equal(got, np.where(mask.T, full, 0.0)), (k, cast)
+            fv = fu.xie_field(s_, t_, 0.1, knn_mask=k, C=3).cpu().numpy()
+            assert np.array_equal(fv, fu.xie_field(s_, t_, 0.1, C=3).cpu().numpy() * mask.T[:, :, None]), (k, cast)
+    # knn_mask beyond the number of targets: every target is a neighbour (k = min(len(targets), knn_mask), :456)
+    assert torch.equal(fu.xie_intersaction(src, tgt, 0.1, 10 ** 6, 3), fu.xie_intersaction(src, tgt, 0.1, -1, 3))

@@ -90,7 +90,7 @@ for n in (4000, 10000, 16000):
               f"{bool(torch.equal(w1, w2) and torch.equal(i1, i2) and torch.equal(w1, w3) and torch.equal(i1, i3))}")
 
 # ---- round 5: the diffuse pass (dnp_xie_rowdots_*, one pass over M for all orders) against the torch matmul it replaced, the
-# kNN mask (brute-force top-k on the device, field_utils._xie_knn_mask) and the float64 forms
+# kNN selection (dnp_xie_knn_*) and the float64 forms
 for n in (4000, 10000):
     gen = torch.Generator().manual_seed(n)
     x = torch.randn(n, 6, generator=gen)
@@ -106,7 +106,24 @@ for n in (4000, 10000):
         gb = n * n * M.element_size() / 1e9
         print(f"N={n:6d} {name} diffuse pass, 5 orders: dnp_xie_rowdots {mn * 1e3:8.1f} us min ({gb / mn * 1e3:6.0f} GB/s of the matrix) | "
               f"torch w @ M.T (rocBLAS) {mnt * 1e3:8.1f} us")
-    med, mn = timed(lambda: fu._xie_knn_mask(pc, pc, 20), reps=5)
-    print(f"N={n:6d} kNN mask (k = 20, brute-force top-k, fp64 distances): {med:8.2f} ms median / {mn:8.2f} min")
+    # the kNN forms: dnp_xie_knn (k-th nearest target per source, fp64 distances) + the masked pair matrix, against the torch
+    # top-k mask of rounds 1-4 (4.8 ms at N = 10 000, k = 20 - plus a [T,S,3] tensor times an fp64 [T,S] mask behind it)
+    kd = torch.empty(n, dtype=torch.float64, device=dev)
+    ki = torch.empty(n, dtype=torch.int64, device=dev)
+    for k in (5, 20, 50):
+        med, mn = timed(lambda: lib.dnp_xie_knn_f32(_lib.ptr(pc), n, 6, _lib.ptr(pc), n, 6, k, _lib.ptr(kd), _lib.ptr(ki), _lib.current_stream()), reps=10)
+        print(f"N={n:6d} dnp_xie_knn_f32 k = {k:2d}: {mn * 1e3:8.1f} us min / {med * 1e3:8.1f} median")
+
+    def topk_mask():
+        d2 = ((pc[:, None, :3].double() - pc[None, :, :3].double()) ** 2).sum(dim=-1) if n <= 4000 else None
+        if d2 is None:
+            return None
+        return d2.topk(20, dim=1, largest=False).indices
+    if n <= 4000:
+        med, mn = timed(topk_mask, reps=5)
+        print(f"N={n:6d} torch fp64 distances + topk(20) (the selection of rounds 1-4): {mn * 1e3:8.1f} us min")
+    med, mn = timed(lambda: fu.xie_intersaction(pc, pc, 0.1, 20, 3), reps=10)
+    med0, mn0 = timed(lambda: fu.xie_intersaction(pc, pc, 0.1, -1, 3), reps=10)
+    print(f"N={n:6d} xie_intersaction with knn_mask = 20: {mn * 1e3:8.1f} us min (selection + masked matrix) | without a mask {mn0 * 1e3:8.1f} us")
     med, mn = timed(lambda: fu.xie_propagation_points_in_order(pc.double(), 0.1, [np.arange(n)], diffuse=True), reps=3)
     print(f"N={n:6d} f64 ordered propagation, 1 order, diffuse: {med:8.2f} ms = {med * 1e3 / n:.2f} us per step (matrix included)")
