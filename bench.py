@@ -253,6 +253,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    if world > 1:
+        # N ranks on one node's cores: torch's default (every core it sees, in every rank) makes the small host-side torch ops of
+        # the set-up thrash - five such ranks on a 16-core share spent 180 s building this workload (tools/gpu_dist_probe.py).
+        # torch.distributed.run sets OMP_NUM_THREADS=1 itself; this covers every other launcher.
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), (os.cpu_count() or world) // world, 4)))
     # one rank per GPU; BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()

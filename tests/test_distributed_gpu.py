@@ -18,6 +18,7 @@ ALL_G6 = [f"{c}_{d}_{w}" for c in ("pf", "sc") for d in ("n", "d") for w in ("nw
 
 
 def _worker(rank, world, port, q):
+    torch.set_num_threads(2)      # several ranks on one box's CPU share: torch's default (every core it sees) times the ranks thrashes
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -80,6 +81,7 @@ def test_hip_ranks_reproduce_the_reference_traces(dev, world):
 
 # ---- the headline workload (G19: 100 000-point sphere, 256 patches) ---------------------------------------------
 def _g19_worker(rank, world, port, q):
+    torch.set_num_threads(2)      # several ranks on one box's CPU share: torch's default (every core it sees) times the ranks thrashes
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -204,6 +206,7 @@ def test_many_clouds_pipelined_on_the_device_equal_the_single_calls(dev):
 
 
 def _one_rank_rccl_worker(port, q):
+    torch.set_num_threads(2)      # several ranks on one box's CPU share: torch's default (every core it sees) times the ranks thrashes
     """A process of its own with a ONE-rank nccl group (all a one-GPU box allows): the asynchronous RCCL path of
     sharded_patch_propagation_many - all_gather_into_tensor(async_op=True) on RCCL's stream under the next cloud's pair kernel,
     interleaved with the diffuse form's all-reduce - against the single calls."""

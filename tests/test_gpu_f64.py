@@ -381,6 +381,7 @@ def test_xie_product_path_with_a_non_permutation_order(dev):
 
 # ---- sharded: two ranks on one card (gloo collectives), float64 ----------------------------------------------------------
 def _worker(rank, world, port, q):
+    torch.set_num_threads(2)      # several ranks on one box's CPU share: torch's default (every core it sees) times the ranks thrashes
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
