@@ -11,7 +11,7 @@ field evaluations `field_grad(pts[patch_k], pts[~patch_k])` (dnp_patch_fields_ti
 one launch per rank, the per-tile interaction partials out of the same kernel's epilogue), the patch
 interaction matrix rows (dnp_interactions_from_tiles) and, for N > 1, the RCCL all-gather of those rows
 that hands every rank what the sequential greedy loop needs - IN THE LAUNCH STREAM'S ORDER, exactly as the
-product's sharded driver issues it (parallel.sharded_patch_propagation -> field_utils._batched_patch_propagation:
+product's sharded driver issues it (parallel.sharded_patch_propagation -> patch_drivers._batched_patch_propagation:
 slabs -> W rows -> synchronous parallel.gather_rows -> greedy loop; the greedy loop needs all of W, so the
 driver cannot overlap the collective with anything).  `value` and `ms_per_step` are THAT step.  At N > 1 over
 RCCL a second timed loop runs the same steps with the all-gather issued asynchronously (two in flight, each
@@ -300,7 +300,7 @@ def main():
     pc_cpu, patches, scramble = headline_workload()
     sizes = np.array([len(p) for p in patches])
     pairs_total = float((sizes * (N_POINTS - sizes)).sum())
-    # layout: the cloud sorted by patch (what the drivers do, field_utils._batched_patch_propagation), so a
+    # layout: the cloud sorted by patch (what the drivers do, patch_drivers._batched_patch_propagation), so a
     # patch is a contiguous row range and every slab / interaction access is coalesced
     off, idx, _ = util.patch_csr(patches, dev)
     pts = pc_cpu.to(dev)[idx].contiguous()
@@ -330,7 +330,7 @@ def main():
     def step(marks=None):
         if marks is not None:
             marks[0].record()
-        if tiles.fused:              # what the drivers do (field_utils._slabs_and_rows), opened up for the event marks
+        if tiles.fused:              # what the drivers do (patch_drivers._slabs_and_rows), opened up for the event marks
             w_part = torch.empty((p_hi - p_lo, tiles.n_tiles, tiles.slots), dtype=torch.float64, device=dev)
             dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part, split)
         else:

@@ -19,6 +19,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import _staging
+
 
 def world():
     if dist.is_available() and dist.is_initialized():
@@ -130,7 +132,7 @@ def sharded_patch_propagation(pts: torch.Tensor, patches, all_patches, diffuse=F
 
     The collectives are issued in the launch stream's order: the greedy loop needs ALL of W, so for one cloud there is
     nothing to overlap the all-gather with (sharded_patch_propagation_many does, across clouds)."""
-    from . import field_utils as fu
+    from . import patch_drivers as fu          # the drivers' own module: where their helpers are looked up (and patched by tests)
 
     rank, size = world()
     with torch.no_grad():
@@ -157,7 +159,7 @@ def sharded_patch_propagation_many(jobs, diffuse=False, force_async=False):
     sharded_patch_propagation job by job (bit for bit); where the backend stages through the host (gloo) or blocks are
     unequal, the gather falls back to the in-order form and only the launch order differs.  force_async: take the
     asynchronous path with a ONE-rank group too (the rehearsal of that path on a one-GPU box; tests)."""
-    from . import field_utils as fu
+    from . import patch_drivers as fu          # the drivers' own module: where their helpers are looked up (and patched by tests)
 
     rank, size = world()
     with torch.no_grad():
@@ -187,7 +189,7 @@ def sharded_patch_propagation_many(jobs, diffuse=False, force_async=False):
             st = fu._batched_end(bw, W, start_t)
             listed = fu._listed_patches(patches, all_patches, work.device) if diffuse else None
             _finish_sharded(fu, pts, work, w, st, patches, diffuse, listed, start_t)
-            traces[live_ids[i]] = fu.last_trace("sharded")
+            traces[live_ids[i]] = _staging.last_trace("sharded")
 
         pending = None
         for i, (pts, patches, all_patches, _, _) in enumerate(live):

@@ -71,7 +71,7 @@ def _global_flip(cloud, stages):
 
 def _write(cloud, transform, export_dir, stages):
     # the reference prints its "warning: %d inf/nan in field_grad" lines inside the offending call; here they are
-    # deferred (field_utils._WarnState) - print whatever is pending before the result is written, not at exit
+    # deferred (_staging._WarnState) - print whatever is pending before the result is written, not at exit
     field_utils.flush_warnings()
     with stages("exporting result", counted=False):
         util.export_pc(transform.inverse(cloud).transpose(0, 1), Path(export_dir) / "final_result.xyz")

@@ -182,7 +182,7 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts,
  * launches below 8 10^9 pairs (profiles/r04_xch_ab.txt: -11 % at 16 of the bench's patches, -3.7 % at 32, -0.5 % at 128).
  * dE and w_part do not depend on source_split (the same fp32 runs, the same fp64 additions in run order); a split patch of
  * more than 512 points is evaluated by one wavefront per tile whatever source_split says, patches of <= 128 points are a
- * single run - the drivers therefore size the tail by its sources, not by a patch count (field_utils._pick_source_split:
+ * single run - the drivers therefore size the tail by its sources, not by a patch count (patch_drivers._pick_source_split:
  * the fewest trailing patches holding 1000 points, 2..8 of them); without both tables a launch with source_split < 0 is the
  * plain one.  (An eight-wavefront item for patches of 513..1024 points was built and measured in round 5 and not kept:
  * profiles/r05_xch_eight_wavefronts.patch.)
@@ -224,7 +224,7 @@ int dnp_patch_fields_tiled_f64(const double* pts, int64_t N, int64_t ld_pts,
 size_t dnp_patch_exchange_bytes(int64_t N, int64_t split_patches);
 int dnp_exchange_init(void* exchange, size_t bytes, void* stream);
 /* The precondition of w_part, checked on the device for callers that cannot check it from patch sizes on the host (the
- * Python drivers do that: field_utils._tile_group_slots): violations[0] (a device int32, NOT cleared here) += the number of
+ * Python drivers do that: patch_drivers._tile_group_slots): violations[0] (a device int32, NOT cleared here) += the number of
  * target tiles of dnp_patch_tile_rows() rows that break it for this w_slots - more than two values of point_patch with
  * w_slots = 2; with w_slots = 3 more than three, or a third value while the second is not the first + 1.  Nonzero means w_part
  * would be wrong for those tiles - use dnp_interactions_f32 / _f64 on the slabs instead.  No synchronisation: read the counter

@@ -90,18 +90,26 @@ def test_product_never_imports_the_oracle():
 
 
 def test_field_utils_re_exports_the_split_modules():
-    """Round 5 moved the staging plumbing and the xie family out of field_utils.py: the public surface is
-    unchanged - every name of __all__ exists, the xie names and last_trace / flush_warnings are the split modules' own objects, and
-    the reference's star-import helpers (torch, np, util) are still there."""
-    from dipole_normal_prop_amd import _staging, xie
+    """Round 5 moved the staging plumbing, the xie family and the drivers out of field_utils.py: the public surface (INTEGRATION.md
+    section 1) is unchanged - every name of __all__ exists, the xie names, the drivers and last_trace / flush_warnings are the split
+    modules' own objects, the reference's star-import helpers (torch, np, util) are still there - and the drivers' knobs exist in ONE
+    place (a copy in field_utils would be a knob that does nothing)."""
+    from dipole_normal_prop_amd import _staging, patch_drivers, point_driver, xie
     from dipole_normal_prop_amd import field_utils as fu
     for name in fu.__all__:
         assert hasattr(fu, name), name
     for name in ("xie_field", "xie_intersaction", "xie_distance", "xie_propagation_points_in_order", "xie_propagation_points_onbfstree",
                  "align_votes"):
         assert getattr(fu, name) is getattr(xie, name)
+    for name in ("strongest_field_propagation", "strongest_field_propagation_reps", "greedy_order_from_interactions", "_batched_begin",
+                 "_batched_end", "_patch_slabs", "_TileTables", "_balanced_blocks", "_pick_source_split"):
+        assert getattr(fu, name) is getattr(patch_drivers, name), name
+    assert fu.strongest_field_propagation_points is point_driver.strongest_field_propagation_points
     assert fu.last_trace is _staging.last_trace and fu.flush_warnings is _staging.flush_warnings and fu._tls is _staging._tls
-    import ast
-    for mod, limit in (("field_utils.py", 1200), ("_staging.py", 400), ("xie.py", 300)):
+    for knob in ("PATCH_MODE", "SLAB_BUDGET_BYTES", "SLAB_BLOCK_BYTES", "SLAB_FREE_CHECK_BYTES", "PATCH_GREEDY_MAX", "TAIL_SOURCES"):
+        assert hasattr(patch_drivers, knob) and not hasattr(fu, knob), knob
+    for knob in ("POINT_GREEDY_FORM", "POINT_GREEDY_GROUPS", "POINT_GREEDY_MAX_PER_GROUP"):
+        assert hasattr(point_driver, knob) and not hasattr(fu, knob), knob
+    for mod, limit in (("field_utils.py", 300), ("patch_drivers.py", 900), ("point_driver.py", 150), ("_staging.py", 400), ("xie.py", 300)):
         n = len(open(os.path.join(ROOT, "dipole_normal_prop_amd", mod)).read().splitlines())
         assert n <= limit, (mod, n)

@@ -12,13 +12,13 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import csr_to_list, load_golden
-from dipole_normal_prop_amd import parallel
+from dipole_normal_prop_amd import field_utils, parallel
 from oracle import dipole_oracle as O
 
 
 class OracleStandIn:
     """CPU stand-ins for the device entry wrappers (dnp_patch_fields_f32 / dnp_interactions_f32 /
-    dnp_patch_greedy / dnp_combine_signed_f32 / dnp_patch_finish_f32).  The worker processes of this test patch them into field_utils
+    dnp_patch_greedy / dnp_combine_signed_f32 / dnp_patch_finish_f32).  The worker processes of this test patch them into patch_drivers
     so that the partition / gather / reduce plumbing of the N>1 path can run without a GPU; the product code
     itself has no such switch."""
 
@@ -86,7 +86,7 @@ def _worker(rank, world, port, start, q):
         torch.set_num_threads(2)
         cloud, patches = _case()
         pts = cloud.clone()
-        from dipole_normal_prop_amd import field_utils as fu
+        from dipole_normal_prop_amd import patch_drivers as fu          # where the drivers look their helpers up
         fu._patch_slabs, fu._interaction_rows = OracleStandIn.slabs, OracleStandIn.interactions
         fu._patch_boxes = lambda work, off, idx: None                            # only the device kernel reads them
         fu._TileTables = lambda swork, sizes: None
@@ -94,7 +94,7 @@ def _worker(rank, world, port, start, q):
         fu._finish_batched = OracleStandIn.finish
         fu._prepare_work = lambda p, w: (p.detach().clone().float(), None)       # CPU working copy (no weights here)
         parallel.sharded_patch_propagation(pts, list(enumerate(patches)), patches, diffuse=True, start_patch=start)
-        tr = fu.last_trace("sharded")
+        tr = field_utils.last_trace("sharded")
         q.put((rank, pts[:, 3:].numpy().copy(), tr["order"].copy(), tr["sigma"].copy(), tr["start"]))
     finally:
         dist.destroy_process_group()
@@ -106,7 +106,7 @@ def _worker_many(rank, world, port, q):
     try:
         torch.set_num_threads(2)
         cloud, patches = _case()
-        from dipole_normal_prop_amd import field_utils as fu
+        from dipole_normal_prop_amd import patch_drivers as fu          # where the drivers look their helpers up
         fu._patch_slabs, fu._interaction_rows = OracleStandIn.slabs, OracleStandIn.interactions
         fu._patch_boxes = lambda work, off, idx: None
         fu._TileTables = lambda swork, sizes: None

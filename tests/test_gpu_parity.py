@@ -11,6 +11,7 @@ import torch
 from conftest import check_chosen, csr_to_list, load_golden, rel_rowwise
 from dipole_normal_prop_amd import _lib
 from dipole_normal_prop_amd import field_utils as fu
+from dipole_normal_prop_amd import patch_drivers as pd, point_driver as ptd  # noqa: E402
 from dipole_normal_prop_amd import util
 from oracle import c_oracle
 from oracle import dipole_oracle as O
@@ -702,7 +703,7 @@ def test_G6_patch_propagation(dev, tag, mode, monkeypatch):
     chosen interactions and final signs of the reference."""
     g = load_golden("G6_patch_propagation")
     cloud, patches, allp, diffuse, w = _patch_case(g, tag)
-    monkeypatch.setattr(fu, "PATCH_MODE", mode)
+    monkeypatch.setattr(pd, "PATCH_MODE", mode)
     pts = cloud.clone().to(dev)
     allp_dev = [p.to(dev) for p in allp]
     if tag.startswith("pf"):      # the filtered lists ARE the patch objects (what the callers pass): fused tail kernel
@@ -730,13 +731,13 @@ def test_G6_slabs_larger_than_the_memory_budget(dev, tag, monkeypatch):
     g = load_golden("G6_patch_propagation")
     cloud, patches, allp, diffuse, w = _patch_case(g, tag)
     per_slab = cloud.shape[0] * 12
-    monkeypatch.setattr(fu, "PATCH_MODE", "batched")
-    monkeypatch.setattr(fu, "SLAB_BUDGET_BYTES", 20 * per_slab)
-    monkeypatch.setattr(fu, "SLAB_FREE_CHECK_BYTES", 0)
-    monkeypatch.setattr(fu, "_free_device_bytes", lambda dev: int(24.5 * per_slab / 0.8))     # budget 24 slabs: blocks of 12
+    monkeypatch.setattr(pd, "PATCH_MODE", "batched")
+    monkeypatch.setattr(pd, "SLAB_BUDGET_BYTES", 20 * per_slab)
+    monkeypatch.setattr(pd, "SLAB_FREE_CHECK_BYTES", 0)
+    monkeypatch.setattr(pd, "_free_device_bytes", lambda dev: int(24.5 * per_slab / 0.8))     # budget 24 slabs: blocks of 12
     calls = []
     real = fu._patch_slabs
-    monkeypatch.setattr(fu, "_patch_slabs", lambda *a, **k: (calls.append((a[4], a[5])), real(*a, **k))[1])
+    monkeypatch.setattr(pd, "_patch_slabs", lambda *a, **k: (calls.append((a[4], a[5])), real(*a, **k))[1])
     pts = cloud.clone().to(dev)
     allp_dev = [p.to(dev) for p in allp]
     filt = [(i, allp_dev[i]) for i, _ in patches]
@@ -762,12 +763,12 @@ def test_G6_slabs_within_the_budget_but_not_within_free_memory(dev, monkeypatch)
     tag = "sc_d_nw"
     cloud, patches, allp, diffuse, w = _patch_case(g, tag)
     per_slab = cloud.shape[0] * 12
-    monkeypatch.setattr(fu, "PATCH_MODE", "batched")
-    monkeypatch.setattr(fu, "SLAB_FREE_CHECK_BYTES", 0)
-    monkeypatch.setattr(fu, "_free_device_bytes", lambda dev: int(24.5 * per_slab / 0.8))     # 72 slabs wanted, 24 fit
+    monkeypatch.setattr(pd, "PATCH_MODE", "batched")
+    monkeypatch.setattr(pd, "SLAB_FREE_CHECK_BYTES", 0)
+    monkeypatch.setattr(pd, "_free_device_bytes", lambda dev: int(24.5 * per_slab / 0.8))     # 72 slabs wanted, 24 fit
     calls = []
     real = fu._patch_slabs
-    monkeypatch.setattr(fu, "_patch_slabs", lambda *a, **k: (calls.append((a[4], a[5])), real(*a, **k))[1])
+    monkeypatch.setattr(pd, "_patch_slabs", lambda *a, **k: (calls.append((a[4], a[5])), real(*a, **k))[1])
     pts = cloud.clone().to(dev)
     allp_dev = [p.to(dev) for p in allp]
     fu.strongest_field_propagation(pts, [(i, allp_dev[i]) for i, _ in patches], allp_dev, diffuse=diffuse)
@@ -898,7 +899,7 @@ def test_G8_point_propagation(dev, tag, monkeypatch):
     g = load_golden("G8_point_propagation")
     name, dflag = tag.split("_")
     if tag == "full_n":
-        monkeypatch.setattr(fu, "POINT_GREEDY_FORM", 1)              # the single-workgroup form on the full cloud
+        monkeypatch.setattr(ptd, "POINT_GREEDY_FORM", 1)              # the single-workgroup form on the full cloud
     cloud = t(g[f"pc_{name}"])
     pts = cloud.clone().to(dev)
     ret = fu.strongest_field_propagation_points(pts, diffuse=(dflag == "d"), starting_point=0)
@@ -916,8 +917,8 @@ def test_G8_point_propagation(dev, tag, monkeypatch):
 def test_G8_multi_workgroup_form_reproduces_the_reference_order(dev, groups, monkeypatch):
     """The multi-workgroup persistent form (chosen above 2048 points), pinned explicitly on ok.xyz: same 10 000-step
     visit order and signs as the reference, for two different workgroup counts."""
-    monkeypatch.setattr(fu, "POINT_GREEDY_FORM", 2)
-    monkeypatch.setattr(fu, "POINT_GREEDY_GROUPS", groups)
+    monkeypatch.setattr(ptd, "POINT_GREEDY_FORM", 2)
+    monkeypatch.setattr(ptd, "POINT_GREEDY_GROUPS", groups)
     g = load_golden("G8_point_propagation")
     cloud = t(g["pc_full"])
     pts = cloud.clone().to(dev)
@@ -970,7 +971,7 @@ def test_capacity_cliff_fallbacks_reproduce_the_reference_traces(dev, monkeypatc
     g = load_golden("G6_patch_propagation")
     tag = "sc_d_w"
     cloud, patches, allp, diffuse, w = _patch_case(g, tag)
-    monkeypatch.setattr(fu, "PATCH_GREEDY_MAX", 0)                    # as if P exceeded the kernels' 16 384 patches
+    monkeypatch.setattr(pd, "PATCH_GREEDY_MAX", 0)                    # as if P exceeded the kernels' 16 384 patches
     pts = cloud.clone().to(dev)
     allp_dev = [p.to(dev) for p in allp]
     fu.strongest_field_propagation(pts, [(i, allp_dev[i]) for i, _ in patches], allp_dev, diffuse=diffuse, weights=w.to(dev))
@@ -982,7 +983,7 @@ def test_capacity_cliff_fallbacks_reproduce_the_reference_traces(dev, monkeypatc
     monkeypatch.undo()
 
     g8 = load_golden("G8_point_propagation")
-    monkeypatch.setattr(fu, "POINT_GREEDY_MAX_PER_GROUP", {torch.float32: 0, torch.float64: 0})   # as if N were too large
+    monkeypatch.setattr(ptd, "POINT_GREEDY_MAX_PER_GROUP", {torch.float32: 0, torch.float64: 0})   # as if N were too large
     for dflag in ("n", "d"):
         cloud = t(g8["pc_sub1000"])
         pts = cloud.clone().to(dev)
@@ -1159,18 +1160,18 @@ def test_G16_float64_full_ok_cloud(dev, form, monkeypatch):
     cloud = t(g8["pc_full"]).double()
     if form == 1:
         sub = cloud[:4096].clone()
-        monkeypatch.setattr(fu, "POINT_GREEDY_FORM", 1)
+        monkeypatch.setattr(ptd, "POINT_GREEDY_FORM", 1)
         a = sub.clone().to(dev)
         fu.strongest_field_propagation_points(a, diffuse=True)
         oa = fu.last_trace("points")["order"]
-        monkeypatch.setattr(fu, "POINT_GREEDY_FORM", 2)
+        monkeypatch.setattr(ptd, "POINT_GREEDY_FORM", 2)
         b = sub.clone().to(dev)
         fu.strongest_field_propagation_points(b, diffuse=True)
         assert np.array_equal(oa, fu.last_trace("points")["order"]) and torch.equal(a, b)
         return
-    monkeypatch.setattr(fu, "POINT_GREEDY_FORM", form)
+    monkeypatch.setattr(ptd, "POINT_GREEDY_FORM", form)
     if form == 2:
-        monkeypatch.setattr(fu, "POINT_GREEDY_GROUPS", 37)
+        monkeypatch.setattr(ptd, "POINT_GREEDY_GROUPS", 37)
     pts = cloud.clone().to(dev)
     out = fu.strongest_field_propagation_points(pts, diffuse=True, starting_point=0)
     assert out.dtype == torch.float64 and out.data_ptr() == pts.data_ptr()
@@ -1229,8 +1230,8 @@ def test_point_greedy_timeout_leaves_pts_untouched_and_the_fallback_equals_the_k
     good = cloud.clone()
     fu.strongest_field_propagation_points(good, diffuse=True)
     good_order = fu.last_trace("points")["order"]
-    monkeypatch.setattr(fu, "POINT_GREEDY_FORM", 3)
-    monkeypatch.setattr(fu, "POINT_GREEDY_GROUPS", 4)
+    monkeypatch.setattr(ptd, "POINT_GREEDY_FORM", 3)
+    monkeypatch.setattr(ptd, "POINT_GREEDY_GROUPS", 4)
     fell = cloud.clone()
     fu.strongest_field_propagation_points(fell, diffuse=True)
     assert "timed out" in capsys.readouterr().out

@@ -14,6 +14,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dipole_normal_prop_amd import field_utils as fu, util  # noqa: E402
+from dipole_normal_prop_amd import patch_drivers as pd, point_driver as ptd  # noqa: E402
 from tools.workloads import headline_workload  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -40,21 +41,21 @@ print("# config 4 (100 000-point sphere, 256 patches, diffuse), ms per call, syn
 print(f"batched driver (the product's path)                          {timed(lambda: fu.strongest_field_propagation(pts.clone(), listed, ranges, diffuse=True), 5):9.2f}")
 other = [(i, p.clone()) for i, p in listed]          # the same indices as separate tensors: the torch tail instead of dnp_patch_finish
 print(f"batched driver, diffuse lists that are not the patch objects  {timed(lambda: fu.strongest_field_propagation(pts.clone(), other, ranges, diffuse=True), 5):9.2f}")
-fu.PATCH_MODE = "sequential"
+pd.PATCH_MODE = "sequential"
 print(f"literal step-by-step form (overlapping patch lists)          {timed(lambda: fu.strongest_field_propagation(pts.clone(), listed, ranges, diffuse=True), 2):9.2f}")
-fu.PATCH_MODE = "auto"
+pd.PATCH_MODE = "auto"
 W = torch.randn(256, 256, dtype=torch.float64, device=dev)
 start = torch.zeros(1, dtype=torch.int64, device=dev)
 t_dev = timed(lambda: fu._greedy_on_device(W, start), 10)
-fu.PATCH_GREEDY_MAX = 0
+pd.PATCH_GREEDY_MAX = 0
 t_host = timed(lambda: fu._greedy_on_device(W, start), 3)
-fu.PATCH_GREEDY_MAX = None
+pd.PATCH_GREEDY_MAX = None
 print(f"greedy loop on W[256,256]: device kernel {t_dev:7.3f} ms | host loop (beyond 16 384 patches) {t_host:7.2f} ms")
 ok = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", "G8_point_propagation.npz"))["pc_full"]).to(dev)[:2000].contiguous()
 t_k = timed(lambda: fu.strongest_field_propagation_points(ok.clone(), diffuse=True), 3)
-keep = dict(fu.POINT_GREEDY_MAX_PER_GROUP)
-fu.POINT_GREEDY_MAX_PER_GROUP = {torch.float32: 0, torch.float64: 0}
+keep = dict(ptd.POINT_GREEDY_MAX_PER_GROUP)
+ptd.POINT_GREEDY_MAX_PER_GROUP = {torch.float32: 0, torch.float64: 0}
 t_s = timed(lambda: fu.strongest_field_propagation_points(ok.clone(), diffuse=True), 1)
-fu.POINT_GREEDY_MAX_PER_GROUP = keep
+ptd.POINT_GREEDY_MAX_PER_GROUP = keep
 print(f"# per-point propagation, 2000 points of ok.xyz: persistent kernel {t_k:8.2f} ms ({t_k * 1e3 / 2000:6.2f} us per step) | "
       f"step-wise fallback (beyond 2^20 points / the per-CU capacity) {t_s:8.1f} ms ({t_s * 1e3 / 2000:6.1f} us per step)")

@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dipole_normal_prop_amd import _lib  # noqa: E402
 from dipole_normal_prop_amd import field_utils as fu  # noqa: E402
+from dipole_normal_prop_amd import point_driver as ptd  # noqa: E402
 from oracle import c_oracle  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -233,12 +234,12 @@ def run(budget=180.0, seed=0):
                 pc = cloud(N)
                 outs = []
                 for form in (1, 2):
-                    fu.POINT_GREEDY_FORM = form
+                    ptd.POINT_GREEDY_FORM = form
                     try:
                         b = pc.clone().to(dev)
                         fu.strongest_field_propagation_points(b, diffuse=True, starting_point=0)
                     finally:
-                        fu.POINT_GREEDY_FORM = 0
+                        ptd.POINT_GREEDY_FORM = 0
                     if sorted(fu.last_trace("points")["order"].tolist()) != list(range(N)):
                         fails.append(f"case {cases}: per-point order is not a permutation (N={N}, form {form})")
                     outs.append((b.cpu(), fu.last_trace("points")["order"].copy()))

@@ -5,6 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from dipole_normal_prop_amd import field_utils as fu
+from dipole_normal_prop_amd import point_driver as ptd  # noqa: E402
 from conftest import load_golden
 from tools.gpu_check import sphere
 
@@ -24,14 +25,14 @@ def run(pc, label):
     print(f"{label}: N={n} {dt*1e3:.1f} ms -> {dt/n*1e6:.2f} us/step, {n*n/dt/1e9:.2f} Gpairs/s", flush=True)
 
 ok = torch.from_numpy(load_golden("G8_point_propagation")["pc_full"])
-fu.POINT_GREEDY_FORM = 1
+ptd.POINT_GREEDY_FORM = 1
 run(ok, "ok.xyz fp32 single-workgroup")
-fu.POINT_GREEDY_FORM = 2
+ptd.POINT_GREEDY_FORM = 2
 run(ok, "ok.xyz fp32 multi-workgroup ")
 run(ok.double(), "ok.xyz fp64 multi-workgroup ")
-fu.POINT_GREEDY_FORM = 1
+ptd.POINT_GREEDY_FORM = 1
 run(ok.double()[:4096], "ok.xyz[:4096] fp64 single-workgroup")
-fu.POINT_GREEDY_FORM = 0
+ptd.POINT_GREEDY_FORM = 0
 run(ok[:2000], "ok.xyz[:2000] fp32 auto")
 run(sphere(30000), "sphere fp32 multi-workgroup")
 run(sphere(100000), "sphere fp32 multi-workgroup")

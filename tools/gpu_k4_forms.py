@@ -6,13 +6,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_golden
 from dipole_normal_prop_amd import field_utils as fu
+from dipole_normal_prop_amd import point_driver as ptd  # noqa: E402
 dev = torch.device("cuda:0")
 ok = torch.from_numpy(load_golden("G8_point_propagation")["pc_full"])
 for dtype in (torch.float32, torch.float64):
     for n in (256, 512, 1024, 2048, 4096):
         row = []
         for form in (1, 2):
-            fu.POINT_GREEDY_FORM = form
+            ptd.POINT_GREEDY_FORM = form
             pc = ok[:n].to(dtype)
             fu.strongest_field_propagation_points(pc.clone().to(dev), diffuse=True); torch.cuda.synchronize()
             ts = []

@@ -6,12 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_golden
 from dipole_normal_prop_amd import field_utils as fu
+from dipole_normal_prop_amd import point_driver as ptd  # noqa: E402
 g = load_golden("G8_point_propagation")
 cloud = torch.from_numpy(g["pc_full"]).cuda()
 ref = None
 for dtype in (torch.float32, torch.float64):
     for groups in (0, 20, 10, 7, 5, 4, 3):
-        fu.POINT_GREEDY_FORM, fu.POINT_GREEDY_GROUPS = 2, groups
+        ptd.POINT_GREEDY_FORM, ptd.POINT_GREEDY_GROUPS = 2, groups
         ts = []
         for _ in range(5):
             pts = cloud.to(dtype).clone(); torch.cuda.synchronize(); t0 = time.perf_counter()
