@@ -207,19 +207,29 @@ __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restri
         asm volatile("" ::"v"(t));                       // a sink: the loads stay, nothing is stored
     }
     double s = 1.0;                                       // the start patch is not flipped
+    // The row of the patch a step adds is requested the moment that patch is known - before the winner's signed value is
+    // extracted and the trace is written - so that the fetch (~0.1 us from this XCD's L2) runs under those ~70
+    // instructions instead of behind them (round 5; DNP_PG_EARLY_ROW=0 builds keep the fetch at the top of the step).
+#ifndef DNP_PG_EARLY_ROW
+#define DNP_PG_EARLY_ROW 1
+#endif
+    double r[EPL];
+    auto fetch_row = [&](int patch) {
+        const double* row = W + (int64_t)patch * P;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {                  // unconditional (clamped) loads: all EPL in flight at once -
+            const int j = e * 64 + lane;                 // a predicated load per entry would be EPL serial round trips
+            r[e] = row[j < P ? j : P - 1];
+        }
+    };
+    if (DNP_PG_EARLY_ROW) fetch_row(cur);
     for (int step = 0; step < P; ++step) {
         if (lane == 0) order_s[step] = cur;
         if ((cur & 63) == lane) {
             visited |= 1ull << (cur >> 6);
             if (s < 0.0) negative |= 1ull << (cur >> 6);
         }
-        const double* row = W + (int64_t)cur * P;
-        double r[EPL];
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {                  // unconditional (clamped) loads: all EPL in flight at once -
-            const int j = e * 64 + lane;                 // a predicated load per entry would be EPL serial round trips
-            r[e] = row[j < P ? j : P - 1];
-        }
+        if (!DNP_PG_EARLY_ROW) fetch_row(cur);
 #pragma unroll
         for (int e = 0; e < EPL; ++e)
             if (e * 64 + lane < P) inter[e] += s * r[e]; // s = +-1: the product is exact
@@ -252,6 +262,10 @@ __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restri
         if (!decided) {
             wave_argmax(bv, bj);
             cur = __builtin_amdgcn_readfirstlane(bj);    // wave-uniform
+        }
+        if (DNP_PG_EARLY_ROW) {
+            fetch_row(cur);
+            __builtin_amdgcn_sched_barrier(0);           // the requests stay HERE, in front of the extraction below
         }
         // the winner's signed interaction lives in lane cur & 63, entry cur >> 6
         double mine = 0.0;
