@@ -154,13 +154,32 @@ __device__ __forceinline__ double dpp_f64_rows(double v) {
     const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(b >> 32), (int)(unsigned)(b >> 32), CTRL, ROWMASK, 0xf, false);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+// v_max_f64 as ONE instruction: __builtin_fmax on a value that came through a DPP move (an integer bit cast) is preceded by a
+// canonicalising v_max_f64 x, x per operand and a register copy for the DPP's `old` operand - seven instructions per butterfly
+// round where three do (the operands here are |I| >= 0, -1 for "none" or +inf: never NaN)
+__device__ __forceinline__ double max_f64_raw(double a, double b) {
+    double d;
+    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// DPP move of a double where every lane has a source lane (quad_perm / row_mirror forms): no `old` value to preserve
+template <int CTRL, int ROWMASK = 0xf>
+__device__ __forceinline__ double dpp_f64_all(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b & 0xffffffffull), CTRL, ROWMASK, 0xf, ROWMASK == 0xf);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), CTRL, ROWMASK, 0xf, ROWMASK == 0xf);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_max_f64(double v) {
-    v = __builtin_fmax(v, dpp_f64<0xB1>(v));
-    v = __builtin_fmax(v, dpp_f64<0x4E>(v));
-    v = __builtin_fmax(v, dpp_f64<0x141>(v));
-    v = __builtin_fmax(v, dpp_f64<0x140>(v));
-    v = __builtin_fmax(v, dpp_f64_rows<0x142, 0xa>(v));   // row_bcast:15 into rows 1 and 3 (the other rows keep their value)
-    v = __builtin_fmax(v, dpp_f64_rows<0x143, 0xc>(v));   // row_bcast:31 into rows 2 and 3
+    v = max_f64_raw(v, dpp_f64_all<0xB1>(v));
+    v = max_f64_raw(v, dpp_f64_all<0x4E>(v));
+    v = max_f64_raw(v, dpp_f64_all<0x141>(v));
+    v = max_f64_raw(v, dpp_f64_all<0x140>(v));
+    // the four row maxima meet in lane 63: row_bcast:15 (lane 15 of rows 0 / 2 into rows 1 / 3), row_bcast:31 (lane 31 into rows 2 / 3).
+    // The rows a move does not write are left with whatever the destination register held - only lane 63 is read, and what feeds
+    // it (row 3 <- row 2's lane 47 in the first move, row 3 <- row 1's lane 31 in the second) is written or untouched input.
+    v = max_f64_raw(v, dpp_f64_all<0x142, 0xa>(v));
+    v = max_f64_raw(v, dpp_f64_all<0x143, 0xc>(v));
     const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffull), 63);
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
@@ -231,16 +250,17 @@ __global__ __launch_bounds__(64) void patch_greedy_kernel(const double* __restri
         }
         if (!DNP_PG_EARLY_ROW) fetch_row(cur);
 #pragma unroll
-        for (int e = 0; e < EPL; ++e)
-            if (e * 64 + lane < P) inter[e] += s * r[e]; // s = +-1: the product is exact
+        for (int e = 0; e < EPL; ++e) inter[e] += s * r[e];   // s = +-1: the product is exact.  (Entries beyond P add the clamped
+        //                                                       load's value: they are "visited" from the start and never read.)
         if (step + 1 == P) break;
         // first maximum of |I_j| in patch order; a NaN counts as the maximum, as in torch.argmax
         double bv = -1.0;
         int bj = 0x7fffffff;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {                  // ascending j within the lane
-            double a = fabs(inter[e]);
-            if (a != a) a = __builtin_huge_val();
+            // min(|I|, +inf): v_min_f64 returns the operand that is not a NaN, so a NaN |I| becomes +inf in one instruction
+            double a;
+            asm("v_min_f64 %0, |%1|, %2" : "=v"(a) : "v"(inter[e]), "v"(__builtin_huge_val()));
             if (!((visited >> e) & 1ull) && a > bv) { bv = a; bj = e * 64 + lane; }
         }
 #ifndef DNP_PG_FAST_ARGMAX   // 0: A/B builds that keep the (value, index) butterfly on every step
