@@ -108,7 +108,9 @@ template <> struct Key<double> {
 
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+    // every lane has a source lane in these forms: no `old` value to keep (update_dpp(v, v, ...) costs a register copy and a wait
+    // state per moved word - round 5, found in the patch greedy loop's ISA)
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
 }
 template <int CTRL>
 __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
@@ -128,7 +130,9 @@ template <int CTRL> __device__ __forceinline__ Key<double> key_dpp(const Key<dou
 #endif
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ unsigned dpp_u32_rows(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xf, false);
+    // rows the mask leaves out keep whatever the destination register held: only lane 63 is read afterwards, and what reaches it
+    // (row 3 <- row 2's lane 47, then row 3 <- row 1's lane 31) is a written or an untouched key
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, CTRL, ROWMASK, 0xf, false);
 }
 template <int CTRL, int ROWMASK> __device__ __forceinline__ Key<float> key_dpp_rows(const Key<float>& k) {
     return Key<float>{((unsigned long long)dpp_u32_rows<CTRL, ROWMASK>((unsigned)(k.k >> 32)) << 32) | dpp_u32_rows<CTRL, ROWMASK>((unsigned)(k.k & 0xffffffffull))};
@@ -151,7 +155,7 @@ __device__ __forceinline__ Key<F> wave_best(Key<F> k) {
     o = key_dpp<0x141>(k); if (o.beats(k)) k = o;
     o = key_dpp<0x140>(k); if (o.beats(k)) k = o;
 #if DNP_K4_ROW_BCAST
-    o = key_dpp_rows<0x142, 0xa>(k); if (o.beats(k)) k = o;     // rows the mask leaves out read their own key: nothing beats itself
+    o = key_dpp_rows<0x142, 0xa>(k); if (o.beats(k)) k = o;
     o = key_dpp_rows<0x143, 0xc>(k); if (o.beats(k)) k = o;
     return key_lane63(k);
 #else

@@ -246,20 +246,23 @@ constexpr int kOrderThreads = 1024;
 // row_bcast:31 fold the four rows into lane 63, v_readlane makes it uniform.  The association is the balanced binary tree over the
 // lanes in index order (IEEE addition commutes, so the mirrored operand orders do not matter): v = v[0::2] + v[1::2], six times.
 // Rounds 3-4 reduced with six __shfl_down steps - six dependent ds_bpermute round trips, ~0.3 us of a 1.5-us step.
+// (The moves carry no `old` operand - a register copy and a wait state per moved word otherwise: in the row_bcast rounds the rows
+// the mask leaves out add whatever the destination register held; only lane 63 is read, and what reaches it - row 3 += row 2's lane
+// 47, then row 3 += row 1's lane 31 - was written or is untouched input.)
 template <int CTRL, int ROWMASK = 0xf>
-__device__ __forceinline__ double xie_dpp_f64(double v, double old) {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v), o = __builtin_bit_cast(unsigned long long, old);
-    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(o & 0xffffffffull), (int)(unsigned)(b & 0xffffffffull), CTRL, ROWMASK, 0xf, false);
-    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(b >> 32), CTRL, ROWMASK, 0xf, false);
+__device__ __forceinline__ double xie_dpp_f64(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b & 0xffffffffull), CTRL, ROWMASK, 0xf, ROWMASK == 0xf);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), CTRL, ROWMASK, 0xf, ROWMASK == 0xf);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
-    v += xie_dpp_f64<0xB1>(v, v);                       // quad_perm [1,0,3,2]
-    v += xie_dpp_f64<0x4E>(v, v);                       // quad_perm [2,3,0,1]
-    v += xie_dpp_f64<0x141>(v, v);                      // row_half_mirror
-    v += xie_dpp_f64<0x140>(v, v);                      // row_mirror: every lane of a row holds the row's sum
-    v += xie_dpp_f64<0x142, 0xa>(v, 0.0);               // row_bcast:15 into rows 1 and 3 (rows 0 and 2 add 0)
-    v += xie_dpp_f64<0x143, 0xc>(v, 0.0);               // row_bcast:31 into rows 2 and 3: lane 63 = (r3 + r2) + (r1 + r0)
+    v += xie_dpp_f64<0xB1>(v);                          // quad_perm [1,0,3,2]
+    v += xie_dpp_f64<0x4E>(v);                          // quad_perm [2,3,0,1]
+    v += xie_dpp_f64<0x141>(v);                         // row_half_mirror
+    v += xie_dpp_f64<0x140>(v);                         // row_mirror: every lane of a row holds the row's sum
+    v += xie_dpp_f64<0x142, 0xa>(v);                    // row_bcast:15 into rows 1 and 3
+    v += xie_dpp_f64<0x143, 0xc>(v);                    // row_bcast:31 into rows 2 and 3: lane 63 = (r3 + r2) + (r1 + r0)
     const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffull), 63);
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
