@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DNP_LIB", os.path.join(_HERE, "libdnp.so"))
 
-ABI_VERSION = 501          # DNP_VERSION of include/dnp.h this binding matches (0.5.0: fp64 patch-driver entry points)
+ABI_VERSION = 502          # DNP_VERSION of include/dnp.h this binding matches (0.5.0: fp64 patch-driver entry points)
 
 _c_i64 = ctypes.c_int64
 _c_p = ctypes.c_void_p
@@ -67,6 +67,9 @@ SIGNATURES = {
                                              _c_p, _c_p, _c_p, _c_p]),
     "dnp_xie_order_f32": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p]),
     "dnp_xie_order_f64": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p]),
+    "dnp_xie_order_workspace_bytes": (ctypes.c_size_t, [_c_i64, _c_i64, ctypes.c_int]),
+    "dnp_xie_order_blocked_f32": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, ctypes.c_size_t, _c_p]),
+    "dnp_xie_order_blocked_f64": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, ctypes.c_size_t, _c_p]),
     "dnp_xie_rowdots_f32": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
     "dnp_xie_rowdots_f64": (ctypes.c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
     "dnp_point_greedy_workspace_bytes": (_c_sz, [_c_i64, ctypes.c_int]),

@@ -289,7 +289,8 @@ template <typename F, int VEC>
 __global__ __launch_bounds__(kOrderThreads) void xie_order_kernel(const F* __restrict__ M, int64_t N,
                                                                  const int64_t* __restrict__ order,
                                                                  F* __restrict__ weights,
-                                                                 F* __restrict__ inter) {
+                                                                 F* __restrict__ inter, const int* __restrict__ only_if) {
+    if (only_if && !only_if[blockIdx.x]) return;           // blocked form (below): only the rows it left to this kernel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t* ord = order + (int64_t)blockIdx.x * N;
     F* w = weights + (int64_t)blockIdx.x * N;
@@ -333,7 +334,8 @@ template <typename F, int VPT, int DEPTH, int VEC>
 __global__ __launch_bounds__(kOrderThreads) void xie_order_reg_kernel(const F* __restrict__ M, int64_t N,
                                                                      const int64_t* __restrict__ order,
                                                                      F* __restrict__ weights,
-                                                                     F* __restrict__ inter) {
+                                                                     F* __restrict__ inter, const int* __restrict__ only_if) {
+    if (only_if && !only_if[blockIdx.x]) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t* ord = order + (int64_t)blockIdx.x * N;
     F* out = inter + (int64_t)blockIdx.x * N;
@@ -447,6 +449,142 @@ __global__ __launch_bounds__(256) void xie_rowdots_kernel(const F* __restrict__ 
         }
 }
 
+// ---- the ordered propagation in BLOCKS (round 5) --------------------------------------------------------------------
+// The visiting order is GIVEN, so the loop  inter[idx_t] = sum_j M[idx_t][j] w[j];  w[idx_t] = sign  is a forward substitution
+// with a sign in it, and it blocks like one.  For a block of kBlkSteps consecutive steps:
+//   rows kernel  (the whole chip, HBM-bound): base[t] = sum_j M[idx_t][j] w[j] over the weights decided BEFORE the block - one
+//                wavefront per step streams its matrix row -, and the block's own kBlkSteps x kBlkSteps corner
+//                sub[s][t] = M[idx_t][idx_s] is gathered from the rows while they are hot;
+//   solve kernel (one wavefront per visiting order): the 256 dependent steps on registers - lane l owns steps 4l..4l+3, a
+//                step reads its sum with v_readlane, takes the sign and adds its column of the corner to the 256 pending sums
+//                (one fused multiply-add per owned step, the column prefetched 8 steps ahead): ~20 ns per step where the
+//                row-per-step kernels above pay one matrix row fetch by one CU and a workgroup barrier (1.24 us at N = 10^4).
+// Same products (M's precision, weights +-1) and fp64 sums; the ORDER of the fp64 additions differs from the row-per-step
+// kernels (columns before the block in lane order, then the block's own steps in visiting order), so `inter` agrees with them
+// to fp64 rounding, not bit for bit.  An order row that is not a permutation of 0..N-1 (a repeated index re-decides a point:
+// the recurrence then needs weight DIFFERENCES) is found by a check kernel and left to the row-per-step kernel: same results
+// as ever for such rows, no host round trip.
+constexpr int kBlkSteps = 256;
+
+__global__ __launch_bounds__(256) void xie_perm_check_kernel(const int64_t* __restrict__ order, int64_t N, int64_t R,
+                                                             unsigned* __restrict__ marks, int* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * N) return;
+    const int64_t r = i / N, idx = order[i];
+    if (idx < 0 || idx >= N) { flags[r] = 1; return; }
+    if (atomicAdd(&marks[r * N + idx], 1u) != 0u) flags[r] = 1;
+}
+
+template <typename F, int VEC>
+__global__ __launch_bounds__(256) void xie_block_rows_kernel(const F* __restrict__ M, int64_t N, const int64_t* __restrict__ order,
+                                                             const F* __restrict__ weights, int64_t t0, int nb,
+                                                             const int* __restrict__ flags, double* __restrict__ base,
+                                                             F* __restrict__ sub) {
+    using V = typename DotVec<F, VEC>::T;
+    const int r = blockIdx.y;
+    if (flags[r]) return;
+    const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= nb) return;
+    const int64_t* ord = order + (int64_t)r * N + t0;
+    const F* row = M + ord[t] * N;
+    const F* w = weights + (int64_t)r * N;
+    double s = 0.0;
+    if (t0 > 0) {                                           // the first block starts from all-zero weights
+#pragma unroll 4
+        for (int64_t j = (int64_t)lane * VEC; j < N; j += 64 * VEC) {      // a lane adds its columns in ascending order
+            const V m = *reinterpret_cast<const V*>(row + j), wv = *reinterpret_cast<const V*>(w + j);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s += (double)(dot_elem<V, VEC>(m, e) * dot_elem<V, VEC>(wv, e));
+        }
+        s = wave_sum_f64(s);
+    }
+    if (lane == 0) base[(int64_t)r * kBlkSteps + t] = s;
+    F* col = sub + (int64_t)r * kBlkSteps * kBlkSteps + t;  // sub[s][t] = M[idx_t][idx_s]: what step s adds to step t's sum
+    for (int q = lane; q < nb; q += 64) col[(int64_t)q * kBlkSteps] = row[ord[q]];
+}
+
+// Four consecutive entries of a corner column, fetched by hand: the solve loop keeps kAhead columns in flight ACROSS its back edge,
+// and for loads the compiler can see its s_waitcnt at the loop header was vmcnt(0) - a full drain every kAhead steps, 250 cycles
+// per step.  Loads issued from inline asm are invisible to that pass; the loop states its own waits (wait_oldest), with the loaded
+// registers passed THROUGH the wait so that nothing that reads them can be scheduled in front of it.
+typedef float xie_v4f __attribute__((ext_vector_type(4)));
+typedef double xie_v2d __attribute__((ext_vector_type(2)));
+template <typename F> struct Col4;
+template <> struct Col4<float> {
+    static constexpr int kLoads = 1;
+    xie_v4f v;
+    __device__ __forceinline__ void issue(const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
+    template <int YOUNGER> __device__ __forceinline__ void wait_oldest() { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(YOUNGER)); }
+    __device__ __forceinline__ double get(int q) const { return (double)v[q]; }
+};
+template <> struct Col4<double> {
+    static constexpr int kLoads = 2;
+    xie_v2d lo, hi;
+    __device__ __forceinline__ void issue(const double* p) {
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(lo), "=&v"(hi) : "v"(p) : "memory");
+    }
+    template <int YOUNGER> __device__ __forceinline__ void wait_oldest() { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(lo), "+v"(hi) : "n"(YOUNGER)); }
+    __device__ __forceinline__ double get(int q) const { return q < 2 ? lo[q] : hi[q - 2]; }
+};
+
+template <typename F>
+__global__ __launch_bounds__(64) void xie_block_solve_kernel(const int64_t* __restrict__ order, int64_t N, int64_t t0, int nb,
+                                                             const int* __restrict__ flags, const double* __restrict__ base,
+                                                             const F* __restrict__ sub, F* __restrict__ weights,
+                                                             F* __restrict__ inter) {
+    const int r = blockIdx.x;
+    if (flags[r]) return;
+    const int lane = threadIdx.x;
+    constexpr int kOwn = kBlkSteps / 64, kAhead = 8;        // steps per lane (4 lane + q), columns in flight
+    static_assert(kOwn == 4 && kAhead % kOwn == 0, "the unrolled step loop assumes 4 steps per lane");
+    double pend[kOwn];
+    F outv[kOwn], outw[kOwn];
+#pragma unroll
+    for (int q = 0; q < kOwn; ++q) {
+        const int u = kOwn * lane + q;
+        pend[q] = u < nb ? base[(int64_t)r * kBlkSteps + u] : 0.0;
+        outv[q] = F(0); outw[q] = F(0);
+    }
+    // the compiler's own loads (base) have landed before the first hand-issued one: its counts and the loop's never mix
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pend[0]), "+v"(pend[1]), "+v"(pend[2]), "+v"(pend[3]));
+    const F* cols = sub + (int64_t)r * kBlkSteps * kBlkSteps + kOwn * lane;
+    Col4<F> ring[kAhead];
+    // column `step` of the corner: this lane's four entries (clamped: a load is issued for EVERY step, so the in-flight count is exact)
+    auto column = [&](int step) { return cols + (int64_t)(step < kBlkSteps ? step : kBlkSteps - 1) * kBlkSteps; };
+#pragma unroll
+    for (int d = 0; d < kAhead; ++d) ring[d].issue(column(d));
+    for (int tb = 0; tb < nb; tb += kAhead) {
+#pragma unroll
+        for (int d = 0; d < kAhead; ++d) {
+            const int t = tb + d;                           // past nb the steps still run (wave-uniform, harmless): their sums are
+            const double v = readlane_f64(pend[d % kOwn], t / kOwn);          // never stored, and every step keeps its load
+            const F vf = (F)v;                              // the sum rounded to M's precision before its sign is taken
+            const double wd = vf < F(0) ? -1.0 : 1.0;
+            if (lane == t / kOwn) { outv[d % kOwn] = vf; outw[d % kOwn] = (F)wd; }
+            ring[d].template wait_oldest<(kAhead - 1) * Col4<F>::kLoads>();
+            double c[kOwn];
+#pragma unroll
+            for (int q = 0; q < kOwn; ++q) c[q] = ring[d].get(q);
+            ring[d].issue(column(t + kAhead));
+            // M[idx_u][idx_t] * w: exact in M's precision (w = +-1), so one fused multiply-add in fp64 is the product rounded
+            // in M's precision and added in fp64
+#pragma unroll
+            for (int q = 0; q < kOwn; ++q) pend[q] = __builtin_fma(c[q], wd, pend[q]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the kAhead loads still in flight: drained before the compiler's loads below
+    const int64_t* ord = order + (int64_t)r * N + t0;
+#pragma unroll
+    for (int q = 0; q < kOwn; ++q) {
+        const int u = kOwn * lane + q;
+        if (u < nb) {
+            const int64_t idx = ord[u];
+            weights[(int64_t)r * N + idx] = outw[q];
+            inter[(int64_t)r * N + idx] = outv[q];
+        }
+    }
+}
+
 template <typename F>
 static int run_xie_pairs(const F* src, int64_t S, int64_t ld_src, const F* tgt, int64_t T, int64_t ld_tgt, F C,
                          int vector_out, F* out, hipStream_t stream, const double* kth_d2 = nullptr,
@@ -493,7 +631,8 @@ static int run_xie_knn(const F* src, int64_t S, int64_t ld_src, const F* tgt, in
 using namespace dnp;
 
 template <typename F>
-static int run_xie_order(const F* M, int64_t N, const int64_t* order, int64_t R, F* weights, F* inter, hipStream_t stream) {
+static int run_xie_order(const F* M, int64_t N, const int64_t* order, int64_t R, F* weights, F* inter, hipStream_t stream,
+                         const int* only_if = nullptr) {
     clear_error();
     DNP_REQUIRE(N >= 0 && R >= 0, "negative size");
     if (N == 0 || R == 0) return DNP_OK;
@@ -509,7 +648,7 @@ static int run_xie_order(const F* M, int64_t N, const int64_t* order, int64_t R,
     constexpr int kVec = f64 ? 2 : 4;                      // 16-byte row loads when the rows allow (N % kVec == 0, M 16-byte aligned)
     const bool wide = N % kVec == 0 && (reinterpret_cast<uintptr_t>(M) & 15) == 0 && (reinterpret_cast<uintptr_t>(weights) & 15) == 0;
     const dim3 grid((unsigned)R), block(kOrderThreads);
-#define DNP_XIE_LAUNCH(KERNEL) hipLaunchKernelGGL((KERNEL), grid, block, 0, stream, M, N, order, weights, inter)
+#define DNP_XIE_LAUNCH(KERNEL) hipLaunchKernelGGL((KERNEL), grid, block, 0, stream, M, N, order, weights, inter, only_if)
     if (!DNP_XIE_ORDER_PLAIN && N <= 4 * kOrderThreads) {
         if (wide) DNP_XIE_LAUNCH((xie_order_reg_kernel<F, 4, f64 ? 3 : 4, kVec>));
         else DNP_XIE_LAUNCH((xie_order_reg_kernel<F, 4, f64 ? 3 : 4, 1>));
@@ -523,6 +662,52 @@ static int run_xie_order(const F* M, int64_t N, const int64_t* order, int64_t R,
 #undef DNP_XIE_LAUNCH
     DNP_CHECK_HIP(hipGetLastError());
     return DNP_OK;
+}
+
+static size_t xie_order_workspace(int64_t N, int64_t R, size_t elem) {
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return pad((size_t)R * sizeof(int)) + pad((size_t)R * (size_t)N * sizeof(unsigned)) + pad((size_t)R * kBlkSteps * sizeof(double)) +
+           pad((size_t)R * kBlkSteps * kBlkSteps * elem);
+}
+
+#ifndef DNP_XIE_BLOCKED_FROM     // points from which the blocked form is used (below: the row-per-step kernels)
+#define DNP_XIE_BLOCKED_FROM 512
+#endif
+template <typename F>
+static int run_xie_order_blocked(const F* M, int64_t N, const int64_t* order, int64_t R, F* weights, F* inter, void* workspace,
+                                 size_t workspace_bytes, hipStream_t stream) {
+    clear_error();
+    DNP_REQUIRE(N >= 0 && R >= 0, "negative size");
+    if (N == 0 || R == 0) return DNP_OK;
+    DNP_REQUIRE(M && order && weights && inter, "NULL pointer");
+    if (N < DNP_XIE_BLOCKED_FROM) return run_xie_order<F>(M, N, order, R, weights, inter, stream);
+    DNP_REQUIRE(R <= 65535, "R=%lld visiting orders exceed one launch", (long long)R);
+    const size_t need = xie_order_workspace(N, R, sizeof(F));
+    if (!workspace || workspace_bytes < need) {
+        set_error("workspace of %zu bytes required, %zu given", need, workspace ? workspace_bytes : (size_t)0);
+        return DNP_EWORKSPACE;
+    }
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    char* p = (char*)workspace;
+    int* flags = (int*)p; p += pad((size_t)R * sizeof(int));
+    unsigned* marks = (unsigned*)p; p += pad((size_t)R * (size_t)N * sizeof(unsigned));
+    double* base = (double*)p; p += pad((size_t)R * kBlkSteps * sizeof(double));
+    F* sub = (F*)p;
+    DNP_CHECK_HIP(hipMemsetAsync(workspace, 0, pad((size_t)R * sizeof(int)) + pad((size_t)R * (size_t)N * sizeof(unsigned)), stream));
+    DNP_CHECK_HIP(hipMemsetAsync(weights, 0, (size_t)R * (size_t)N * sizeof(F), stream));     // rows kernel reads them from block 1 on
+    hipLaunchKernelGGL(xie_perm_check_kernel, dim3((unsigned)ceil_div(R * N, (int64_t)256)), dim3(256), 0, stream, order, N, R, marks, flags);
+    constexpr int kVec = sizeof(F) == 8 ? 2 : 4;
+    const bool wide = N % kVec == 0 && (reinterpret_cast<uintptr_t>(M) & 15) == 0 && (reinterpret_cast<uintptr_t>(weights) & 15) == 0;
+    for (int64_t t0 = 0; t0 < N; t0 += kBlkSteps) {
+        const int nb = (int)((N - t0) < kBlkSteps ? (N - t0) : kBlkSteps);
+        const dim3 grid((unsigned)ceil_div(nb, 4), (unsigned)R);
+        if (wide) hipLaunchKernelGGL((xie_block_rows_kernel<F, kVec>), grid, dim3(256), 0, stream, M, N, order, weights, t0, nb, flags, base, sub);
+        else hipLaunchKernelGGL((xie_block_rows_kernel<F, 1>), grid, dim3(256), 0, stream, M, N, order, weights, t0, nb, flags, base, sub);
+        hipLaunchKernelGGL((xie_block_solve_kernel<F>), dim3((unsigned)R), dim3(64), 0, stream, order, N, t0, nb, flags, base, sub, weights, inter);
+    }
+    DNP_CHECK_HIP(hipGetLastError());
+    // rows that are not permutations: the row-per-step kernel, which zeroes and fills their outputs itself
+    return run_xie_order<F>(M, N, order, R, weights, inter, stream, flags);
 }
 
 template <typename F>
@@ -586,6 +771,21 @@ int dnp_xie_order_f32(const float* M, int64_t N, const int64_t* order, int64_t R
 int dnp_xie_order_f64(const double* M, int64_t N, const int64_t* order, int64_t R, double* weights, double* inter,
                       void* stream) {
     return run_xie_order<double>(M, N, order, R, weights, inter, (hipStream_t)stream);
+}
+
+size_t dnp_xie_order_workspace_bytes(int64_t N, int64_t R, int elem_bytes) {
+    if (N <= 0 || R <= 0 || N < DNP_XIE_BLOCKED_FROM) return 256;
+    return xie_order_workspace(N, R, (size_t)(elem_bytes == 8 ? 8 : 4));
+}
+
+int dnp_xie_order_blocked_f32(const float* M, int64_t N, const int64_t* order, int64_t R, float* weights, float* inter,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    return run_xie_order_blocked<float>(M, N, order, R, weights, inter, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int dnp_xie_order_blocked_f64(const double* M, int64_t N, const int64_t* order, int64_t R, double* weights, double* inter,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    return run_xie_order_blocked<double>(M, N, order, R, weights, inter, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int dnp_xie_rowdots_f32(const float* M, int64_t N, const float* weights, int64_t R, float* out, void* stream) {

@@ -4,12 +4,14 @@ with its vote, xie_propagation_points_onbfstree (:657-710) - same names, argumen
 loop, its diffuse pass and the kNN mask run in csrc/dnp_xie.hip behind the C ABI (dnp_xie_pairs_*, dnp_xie_knn_*, dnp_xie_pairs_knn_*,
 dnp_xie_order_*, dnp_xie_rowdots_*), in the
 cloud's own precision (float64 clouds in float64).  Split out of field_utils.py in round 5; every public name is re-exported there."""
+import ctypes
+
 import numpy as np
 import torch
 
 from . import _lib
 from . import util
-from ._staging import _compute_device, _ld, _on_device, _set_trace, _stage, _work_dtype
+from ._staging import _compute_device, _ld, _on_device, _set_trace, _stage, _work_dtype, _workspace
 
 
 def _xie_pairs(source, target, C, vector_out, knn_mask=-1):
@@ -89,9 +91,14 @@ def xie_propagation_points_in_order(pts: torch.Tensor, eps, order, diffuse=False
         weights = torch.empty((T, N), dtype=wd, device=dev)
         inter = torch.empty((T, N), dtype=wd, device=dev)
         f64 = wd == torch.float64
+        # the blocked form (csrc/dnp_xie.hip): 256 steps per block - one HBM-bound launch for the block's row sums, one wavefront
+        # per order for its dependent steps; rows of `order` that are not permutations go to the row-per-step kernel inside the call
+        stream_handle = torch.cuda.current_stream(dev).cuda_stream
+        ws = _workspace(lib.dnp_xie_order_workspace_bytes(N, T, 8 if f64 else 4), dev, stream_handle)
         with _on_device(dev):
-            rc = (lib.dnp_xie_order_f64 if f64 else lib.dnp_xie_order_f32)(_lib.ptr(M), N, _lib.ptr(order_t), T, _lib.ptr(weights),
-                                                                          _lib.ptr(inter), _lib.current_stream())
+            rc = (lib.dnp_xie_order_blocked_f64 if f64 else lib.dnp_xie_order_blocked_f32)(
+                _lib.ptr(M), N, _lib.ptr(order_t), T, _lib.ptr(weights), _lib.ptr(inter), _lib.ptr(ws), ws.numel(),
+                ctypes.c_void_p(stream_handle))
         _lib.check(rc)
         if diffuse:
             # interactions[t][i] = sum_j M[i][j] * w[t][j] (:597-603): one pass over M for all T weight vectors

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DNP_VERSION 501 /* 0.5.1: + dnp_xie_knn_*, dnp_xie_pairs_knn_* (0.5.0: the fp64 patch-driver entry points, dnp_xie_order_f64, dnp_xie_rowdots_*) */
+#define DNP_VERSION 502 /* 0.5.2: + dnp_xie_order_blocked_*; 0.5.1: + dnp_xie_knn_*, dnp_xie_pairs_knn_* (0.5.0: the fp64 patch-driver entry points, dnp_xie_order_f64, dnp_xie_rowdots_*) */
 
 enum {
     DNP_OK = 0,
@@ -410,6 +410,13 @@ int dnp_merge_cells(const int32_t* cell_ijk, const int64_t* cell_size, int64_t C
  * never visits - a row that repeats an index - come back 0, as the reference's torch.zeros).  _f64: float64 matrices (a
  * float64 cloud, field_utils.py:581-595 computes in pts.dtype).  Products are rounded in M's precision, row sums run in fp64.
  *
+ * dnp_xie_order_blocked (round 5): the same loop evaluated in blocks of 256 steps - per block one HBM-bound launch sums each step's
+ * matrix row against the weights decided before the block (and gathers the block's own 256 x 256 corner), then one wavefront per
+ * visiting order runs the 256 dependent steps on registers.  Same products, fp64 sums in another order: `inter` agrees with
+ * dnp_xie_order to fp64 rounding.  Order rows that are not permutations of 0..N-1 are detected on the device and evaluated by
+ * dnp_xie_order's kernels (identical results for them); below 512 points the call IS dnp_xie_order.  workspace:
+ * dnp_xie_order_workspace_bytes(N, R, sizeof element) bytes of device memory, contents irrelevant.
+ *
  * dnp_xie_rowdots: the diffuse pass behind that loop (field_utils.py:597-603): out[r][i] = sum_j M[i][j] * w[r][j] for the R
  * weight vectors in one pass over M ([R, N] in, [R, N] out; one wavefront per matrix row, HBM-bound).
  */
@@ -429,6 +436,11 @@ int dnp_xie_order_f32(const float* M, int64_t N, const int64_t* order, int64_t R
                       void* stream);
 int dnp_xie_order_f64(const double* M, int64_t N, const int64_t* order, int64_t R, double* weights, double* inter,
                       void* stream);
+size_t dnp_xie_order_workspace_bytes(int64_t N, int64_t R, int elem_bytes);
+int dnp_xie_order_blocked_f32(const float* M, int64_t N, const int64_t* order, int64_t R, float* weights, float* inter,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int dnp_xie_order_blocked_f64(const double* M, int64_t N, const int64_t* order, int64_t R, double* weights, double* inter,
+                              void* workspace, size_t workspace_bytes, void* stream);
 int dnp_xie_rowdots_f32(const float* M, int64_t N, const float* weights, int64_t R, float* out, void* stream);
 int dnp_xie_rowdots_f64(const double* M, int64_t N, const double* weights, int64_t R, double* out, void* stream);
 

@@ -425,3 +425,41 @@ def test_G21_float64_sharded_over_two_ranks(dev):
         assert np.abs(chosen - g["chosen_g6_pf_d_w"]).max() <= 1e-10 * np.abs(g["chosen_g6_pf_d_w"]).max()
         assert np.abs(out[:, 3:] - g["normals_g6_pf_d_w"]).max() <= 4e-16
     assert np.array_equal(res[0][5], res[1][5])
+
+
+@pytest.mark.parametrize("n,dtype", [(520, torch.float32), (1001, torch.float32), (4096, torch.float32), (10000, torch.float32),
+                                     (777, torch.float64), (4100, torch.float64)])
+def test_xie_order_blocked_form_equals_the_row_per_step_kernels(dev, n, dtype):
+    """dnp_xie_order_blocked_* (256-step blocks: row sums against the weights decided before the block in one launch, the block's
+    dependent steps by one wavefront per order) against dnp_xie_order_*: the same sign at every step of every order, `inter` equal up
+    to the order of the fp64 additions - and, in the SAME call, an order row that is not a permutation (one index twice, one never),
+    which the blocked entry point hands to the row-per-step kernel: bit for bit what dnp_xie_order gives, 0 for the unvisited point.
+    Sizes: one block and a bit, an odd N (scalar loads), whole blocks, the bench's 10 000; buffers poisoned first."""
+    lib = _lib.require_device()
+    gen = torch.Generator().manual_seed(n)
+    M = (torch.rand(n, n, generator=gen, dtype=torch.float64) - 0.5).to(dtype).to(dev)
+    rows = [np.random.default_rng(s).permutation(n).astype(np.int64) for s in (1, 2, 3)]
+    bad = rows[1].copy()
+    missing, repeated = int(bad[n // 2]), int(bad[n // 3])
+    bad[n // 2] = repeated
+    order_t = t(np.stack([rows[0], bad, rows[2]])).to(dev)
+    f64 = dtype == torch.float64
+    w_seq = torch.full((3, n), 7.0, dtype=dtype, device=dev)
+    i_seq = torch.full((3, n), -7.0, dtype=dtype, device=dev)
+    assert (lib.dnp_xie_order_f64 if f64 else lib.dnp_xie_order_f32)(_lib.ptr(M), n, _lib.ptr(order_t), 3, _lib.ptr(w_seq), _lib.ptr(i_seq),
+                                                                     _lib.current_stream()) == 0
+    w_blk = torch.full((3, n), 5.0, dtype=dtype, device=dev)
+    i_blk = torch.full((3, n), -5.0, dtype=dtype, device=dev)
+    nbytes = lib.dnp_xie_order_workspace_bytes(n, 3, 8 if f64 else 4)
+    ws = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device=dev)          # contents irrelevant: poisoned
+    fn = lib.dnp_xie_order_blocked_f64 if f64 else lib.dnp_xie_order_blocked_f32
+    assert fn(_lib.ptr(M), n, _lib.ptr(order_t), 3, _lib.ptr(w_blk), _lib.ptr(i_blk), _lib.ptr(ws), nbytes, _lib.current_stream()) == 0
+    assert fn(_lib.ptr(M), n, _lib.ptr(order_t), 3, _lib.ptr(w_blk), _lib.ptr(i_blk), _lib.ptr(ws), max(nbytes - 256, 0),
+              _lib.current_stream()) != 0                                        # a workspace that is too small is refused
+    ws2, is2, wb, ib = w_seq.cpu().numpy(), i_seq.cpu().numpy(), w_blk.cpu().numpy(), i_blk.cpu().numpy()
+    assert np.array_equal(wb[1], ws2[1]) and np.array_equal(ib[1], is2[1])       # the non-permutation row: the same kernel
+    assert ib[1, missing] == 0 and wb[1, missing] == 0
+    for r in (0, 2):
+        assert np.array_equal(wb[r], ws2[r]), r                                  # every sign decision
+        scale = np.abs(is2[r]).max()
+        assert np.abs(ib[r] - is2[r]).max() <= (2e-7 if not f64 else 1e-13) * scale, r

@@ -89,6 +89,26 @@ for n in (4000, 10000, 16000):
         print(f"N={n:6d}   weights and interactions bit-identical between the three forms: "
               f"{bool(torch.equal(w1, w2) and torch.equal(i1, i2) and torch.equal(w1, w3) and torch.equal(i1, i3))}")
 
+# ---- round 5: the blocked form of the ordered propagation (dnp_xie_order_blocked_*) against the row-per-step kernels
+for n in (1000, 4000, 10000, 16000):
+    gen = torch.Generator().manual_seed(n + 1)
+    for dt, name in ((torch.float32, "f32"), (torch.float64, "f64")):
+        M = (torch.rand(n, n, generator=gen, dtype=torch.float32) - 0.5).to(dt).to(dev)
+        for R in (1, 5):
+            order_t = torch.from_numpy(np.stack([np.random.default_rng(s).permutation(n) for s in range(R)]).astype(np.int64)).to(dev)
+            w1, i1 = torch.empty((R, n), dtype=dt, device=dev), torch.empty((R, n), dtype=dt, device=dev)
+            w2, i2 = torch.empty_like(w1), torch.empty_like(i1)
+            f64 = dt == torch.float64
+            seq = lib.dnp_xie_order_f64 if f64 else lib.dnp_xie_order_f32
+            blk = lib.dnp_xie_order_blocked_f64 if f64 else lib.dnp_xie_order_blocked_f32
+            nbytes = lib.dnp_xie_order_workspace_bytes(n, R, 8 if f64 else 4)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            ms, _ = timed(lambda: seq(_lib.ptr(M), n, _lib.ptr(order_t), R, _lib.ptr(w1), _lib.ptr(i1), _lib.current_stream()), reps=5)
+            mb, _ = timed(lambda: blk(_lib.ptr(M), n, _lib.ptr(order_t), R, _lib.ptr(w2), _lib.ptr(i2), _lib.ptr(ws), nbytes, _lib.current_stream()), reps=5)
+            print(f"N={n:6d} {name} {R} order(s): row-per-step {ms:8.3f} ms ({ms * 1e3 / n:5.2f} us per step) | blocked {mb:8.3f} ms "
+                  f"({mb * 1e3 / n:5.3f} us per step, {ms / mb:4.1f}x) | same signs: {bool(torch.equal(w1, w2))}", flush=True)
+        del M
+
 # ---- round 5: the diffuse pass (dnp_xie_rowdots_*, one pass over M for all orders) against the torch matmul it replaced, the
 # kNN selection (dnp_xie_knn_*) and the float64 forms
 for n in (4000, 10000):
