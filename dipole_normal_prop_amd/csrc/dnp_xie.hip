@@ -475,32 +475,40 @@ __global__ __launch_bounds__(256) void xie_perm_check_kernel(const int64_t* __re
     if (atomicAdd(&marks[r * N + idx], 1u) != 0u) flags[r] = 1;
 }
 
+constexpr int kBlkAhead = 8;                               // corner columns the solve kernel keeps in flight
+constexpr int kBlkCols = kBlkSteps + kBlkAhead;            // ... and reads past the last step without a clamp: the corner has that many
 template <typename F, int VEC>
 __global__ __launch_bounds__(256) void xie_block_rows_kernel(const F* __restrict__ M, int64_t N, const int64_t* __restrict__ order,
                                                              const F* __restrict__ weights, int64_t t0, int nb,
                                                              const int* __restrict__ flags, double* __restrict__ base,
                                                              F* __restrict__ sub) {
     using V = typename DotVec<F, VEC>::T;
-    const int r = blockIdx.y;
+    const int r = blockIdx.y, t = blockIdx.x;              // one workgroup per step of the block: four wavefronts share its matrix row
     if (flags[r]) return;
-    const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= nb) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t* ord = order + (int64_t)r * N + t0;
     const F* row = M + ord[t] * N;
     const F* w = weights + (int64_t)r * N;
-    double s = 0.0;
+    __shared__ double part[4];
     if (t0 > 0) {                                           // the first block starts from all-zero weights
+        double s = 0.0;
 #pragma unroll 4
-        for (int64_t j = (int64_t)lane * VEC; j < N; j += 64 * VEC) {      // a lane adds its columns in ascending order
+        for (int64_t j = (int64_t)tid * VEC; j < N; j += 256 * VEC) {      // a thread adds its columns in ascending order
             const V m = *reinterpret_cast<const V*>(row + j), wv = *reinterpret_cast<const V*>(w + j);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) s += (double)(dot_elem<V, VEC>(m, e) * dot_elem<V, VEC>(wv, e));
         }
         s = wave_sum_f64(s);
+        if (lane == 0) part[wave] = s;
+        __syncthreads();
+        if (tid == 0) base[(int64_t)r * kBlkSteps + t] = ((part[0] + part[1]) + part[2]) + part[3];
+    } else if (tid == 0) {
+        base[(int64_t)r * kBlkSteps + t] = 0.0;
     }
-    if (lane == 0) base[(int64_t)r * kBlkSteps + t] = s;
-    F* col = sub + (int64_t)r * kBlkSteps * kBlkSteps + t;  // sub[s][t] = M[idx_t][idx_s]: what step s adds to step t's sum
-    for (int q = lane; q < nb; q += 64) col[(int64_t)q * kBlkSteps] = row[ord[q]];
+    // the block's own corner: sub[s][t] = M[idx_t][idx_s] = what step s adds to the sum of a LATER step t; 0 for t <= s, so the
+    // solve kernel can add whole columns and still end with every step's sum as it stood when the step was taken
+    F* col = sub + (int64_t)r * kBlkCols * kBlkSteps + t;
+    for (int q = tid; q < nb; q += 256) col[(int64_t)q * kBlkSteps] = t > q ? row[ord[q]] : F(0);
 }
 
 // Four consecutive entries of a corner column, fetched by hand: the solve loop keeps kAhead columns in flight ACROSS its back edge,
@@ -535,52 +543,56 @@ __global__ __launch_bounds__(64) void xie_block_solve_kernel(const int64_t* __re
     const int r = blockIdx.x;
     if (flags[r]) return;
     const int lane = threadIdx.x;
-    constexpr int kOwn = kBlkSteps / 64, kAhead = 8;        // steps per lane (4 lane + q), columns in flight
+    constexpr int kOwn = kBlkSteps / 64, kAhead = kBlkAhead;   // steps per lane (4 lane + q), columns in flight
     static_assert(kOwn == 4 && kAhead % kOwn == 0, "the unrolled step loop assumes 4 steps per lane");
     double pend[kOwn];
-    F outv[kOwn], outw[kOwn];
 #pragma unroll
     for (int q = 0; q < kOwn; ++q) {
         const int u = kOwn * lane + q;
         pend[q] = u < nb ? base[(int64_t)r * kBlkSteps + u] : 0.0;
-        outv[q] = F(0); outw[q] = F(0);
     }
     // the compiler's own loads (base) have landed before the first hand-issued one: its counts and the loop's never mix
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(pend[0]), "+v"(pend[1]), "+v"(pend[2]), "+v"(pend[3]));
-    const F* cols = sub + (int64_t)r * kBlkSteps * kBlkSteps + kOwn * lane;
+    // column s of the corner, this lane's four entries.  A load is issued for EVERY step of the main loop (the corner has kAhead
+    // columns to spare), so the in-flight count the waits rely on is exact.
+    const F* next = sub + (int64_t)r * kBlkCols * kBlkSteps + kOwn * lane;
     Col4<F> ring[kAhead];
-    // column `step` of the corner: this lane's four entries (clamped: a load is issued for EVERY step, so the in-flight count is exact)
-    auto column = [&](int step) { return cols + (int64_t)(step < kBlkSteps ? step : kBlkSteps - 1) * kBlkSteps; };
 #pragma unroll
-    for (int d = 0; d < kAhead; ++d) ring[d].issue(column(d));
-    for (int tb = 0; tb < nb; tb += kAhead) {
+    for (int d = 0; d < kAhead; ++d) { ring[d].issue(next); next += kBlkSteps; }
+    auto step = [&](int t, int d) {
+        // the step's sum as it stands: nothing is added to it any more (columns are 0 up to and including their own step)
+        const double v = readlane_f64(pend[d % kOwn], t / kOwn);
+        const double wd = (F)v < F(0) ? -1.0 : 1.0;        // the sum rounded to M's precision before its sign is taken
+        // M[idx_u][idx_t] * w is exact in M's precision (w = +-1): one fused multiply-add in fp64 = that product added in fp64
+#pragma unroll
+        for (int q = 0; q < kOwn; ++q) pend[q] = __builtin_fma(ring[d].get(q), wd, pend[q]);
+    };
+    int tb = 0;
+    for (; tb + kAhead <= nb; tb += kAhead) {
 #pragma unroll
         for (int d = 0; d < kAhead; ++d) {
-            const int t = tb + d;                           // past nb the steps still run (wave-uniform, harmless): their sums are
-            const double v = readlane_f64(pend[d % kOwn], t / kOwn);          // never stored, and every step keeps its load
-            const F vf = (F)v;                              // the sum rounded to M's precision before its sign is taken
-            const double wd = vf < F(0) ? -1.0 : 1.0;
-            if (lane == t / kOwn) { outv[d % kOwn] = vf; outw[d % kOwn] = (F)wd; }
             ring[d].template wait_oldest<(kAhead - 1) * Col4<F>::kLoads>();
-            double c[kOwn];
-#pragma unroll
-            for (int q = 0; q < kOwn; ++q) c[q] = ring[d].get(q);
-            ring[d].issue(column(t + kAhead));
-            // M[idx_u][idx_t] * w: exact in M's precision (w = +-1), so one fused multiply-add in fp64 is the product rounded
-            // in M's precision and added in fp64
-#pragma unroll
-            for (int q = 0; q < kOwn; ++q) pend[q] = __builtin_fma(c[q], wd, pend[q]);
+            step(tb + d, d);
+            ring[d].issue(next);
+            next += kBlkSteps;
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the kAhead loads still in flight: drained before the compiler's loads below
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the tail (nb % kAhead steps) and the stores below: everything has landed
+#pragma unroll
+    for (int d = 0; d < kAhead; ++d)
+        if (tb + d < nb) {                                  // wave-uniform
+            ring[d].template wait_oldest<0>();
+            step(tb + d, d);
+        }
     const int64_t* ord = order + (int64_t)r * N + t0;
 #pragma unroll
     for (int q = 0; q < kOwn; ++q) {
         const int u = kOwn * lane + q;
         if (u < nb) {
             const int64_t idx = ord[u];
-            weights[(int64_t)r * N + idx] = outw[q];
-            inter[(int64_t)r * N + idx] = outv[q];
+            const F vf = (F)pend[q];
+            weights[(int64_t)r * N + idx] = vf < F(0) ? F(-1) : F(1);
+            inter[(int64_t)r * N + idx] = vf;
         }
     }
 }
@@ -667,7 +679,7 @@ static int run_xie_order(const F* M, int64_t N, const int64_t* order, int64_t R,
 static size_t xie_order_workspace(int64_t N, int64_t R, size_t elem) {
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     return pad((size_t)R * sizeof(int)) + pad((size_t)R * (size_t)N * sizeof(unsigned)) + pad((size_t)R * kBlkSteps * sizeof(double)) +
-           pad((size_t)R * kBlkSteps * kBlkSteps * elem);
+           pad((size_t)R * kBlkCols * kBlkSteps * elem);
 }
 
 #ifndef DNP_XIE_BLOCKED_FROM     // points from which the blocked form is used (below: the row-per-step kernels)
@@ -700,7 +712,7 @@ static int run_xie_order_blocked(const F* M, int64_t N, const int64_t* order, in
     const bool wide = N % kVec == 0 && (reinterpret_cast<uintptr_t>(M) & 15) == 0 && (reinterpret_cast<uintptr_t>(weights) & 15) == 0;
     for (int64_t t0 = 0; t0 < N; t0 += kBlkSteps) {
         const int nb = (int)((N - t0) < kBlkSteps ? (N - t0) : kBlkSteps);
-        const dim3 grid((unsigned)ceil_div(nb, 4), (unsigned)R);
+        const dim3 grid((unsigned)nb, (unsigned)R);
         if (wide) hipLaunchKernelGGL((xie_block_rows_kernel<F, kVec>), grid, dim3(256), 0, stream, M, N, order, weights, t0, nb, flags, base, sub);
         else hipLaunchKernelGGL((xie_block_rows_kernel<F, 1>), grid, dim3(256), 0, stream, M, N, order, weights, t0, nb, flags, base, sub);
         hipLaunchKernelGGL((xie_block_solve_kernel<F>), dim3((unsigned)R), dim3(64), 0, stream, order, N, t0, nb, flags, base, sub, weights, inter);

@@ -2,7 +2,7 @@
 (field_utils.py:431-526), the ordered sign propagation xie_propagation_points_in_order (:569-605) and the BFS-route propagation
 with its vote, xie_propagation_points_onbfstree (:657-710) - same names, argument order and defaults; the pair matrix, the ordered
 loop, its diffuse pass and the kNN mask run in csrc/dnp_xie.hip behind the C ABI (dnp_xie_pairs_*, dnp_xie_knn_*, dnp_xie_pairs_knn_*,
-dnp_xie_order_*, dnp_xie_rowdots_*), in the
+dnp_xie_order_blocked_*, dnp_xie_rowdots_*), in the
 cloud's own precision (float64 clouds in float64).  Split out of field_utils.py in round 5; every public name is re-exported there."""
 import ctypes
 
