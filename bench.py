@@ -199,11 +199,11 @@ def other_configs(dev, fu, util, pts_sorted, patch_ranges):
     t = timed(lambda: fu.strongest_field_propagation(pts_sorted.clone(), list(enumerate(patch_ranges)), patch_ranges,
                                                      diffuse=True), 5)
     out["config4_patch_driver_end_to_end"] = {"points": N_POINTS, "patches": N_PATCHES, "ms": t * 1e3}
-    t = timed(lambda: fu.field_grad(pts_sorted, pts_sorted), 5)
+    t = timed(lambda: fu.field_grad(pts_sorted, pts_sorted), 10)
     out["allpairs_100k_field_grad"] = {"points": N_POINTS, "ms": t * 1e3, "pairs_per_s": float(N_POINTS) ** 2 / t}
     g = torch.Generator().manual_seed(3)
     tgt = (pts_sorted[:, :3].cpu() + 1e-3 * torch.randn(N_POINTS, 3, generator=g)).to(dev)
-    t = timed(lambda: fu.reference_field(pts_sorted, tgt), 5)
+    t = timed(lambda: fu.reference_field(pts_sorted, tgt), 10)
     out["config5_reference_field_100k_to_100k"] = {"sources": N_POINTS, "targets": N_POINTS, "ms": t * 1e3,
                                                    "pairs_per_s": float(N_POINTS) ** 2 / t, "dtype": "f32"}
     # ---- the float64 entry points (round 5; the reference's socket path hands float64 clouds to the same functions): pairs/s
@@ -212,16 +212,27 @@ def other_configs(dev, fu, util, pts_sorted, patch_ranges):
         return {"ms": t * 1e3, "pairs_per_s": pairs / t, "dtype": "f64", "flop_per_pair": flop,
                 "frac_of_fp64_valu_peak": pairs * flop / t / 1e12 / FP64_VALU_PEAK_TFLOPS}
     grid = util.gen_grid().to(dev)
-    t = timed(lambda: fu.potential(pts_sorted, grid), 20)
+    t = timed(lambda: fu.potential(pts_sorted, grid), 200)       # 60-us calls: a window long enough to dilute one host hiccup
     out["potential_100k_x_1000_lattice"] = {"ms": t * 1e3, "pairs_per_s": float(N_POINTS) * grid.shape[0] / t, "dtype": "f32"}
     pts64, tgt64, grid64 = pts_sorted.double(), tgt.double(), grid.double()
-    out["potential_100k_x_1000_lattice_f64"] = f64_leg(float(N_POINTS) * grid.shape[0], timed(lambda: fu.potential(pts64, grid64), 20), 13)
+    out["potential_100k_x_1000_lattice_f64"] = f64_leg(float(N_POINTS) * grid.shape[0], timed(lambda: fu.potential(pts64, grid64), 200), 13)
     out["allpairs_100k_field_grad_f64"] = f64_leg(float(N_POINTS) ** 2, timed(lambda: fu.field_grad(pts64, pts64), 3))
     out["config5_reference_field_100k_to_100k_f64"] = f64_leg(float(N_POINTS) ** 2, timed(lambda: fu.reference_field(pts64, tgt64), 3))
     t = timed(lambda: fu.strongest_field_propagation(pts64.clone(), list(enumerate(patch_ranges)), patch_ranges, diffuse=True), 3)
     out["config4_patch_driver_end_to_end_f64"] = dict(f64_leg(float(N_POINTS) ** 2, t), points=N_POINTS, patches=N_PATCHES,
                                                       note="float64 cloud: fp64 slabs, W, combine and tail (dnp_patch_fields_tiled_f64 ...)")
     del pts64, tgt64, grid64
+    # the fork's ordered propagation (the socket path's xie_propagation_points_onbfstree runs it once per route): the
+    # interaction matrix, the blocked ordered loop and the diffuse pass for 5 visiting orders of 10 000 points, orders uploaded per call
+    nx = 10000
+    xg = torch.randn(nx, 6, generator=torch.Generator().manual_seed(5))
+    xpc = torch.cat([0.4 * xg[:, :3] / xg[:, :3].norm(dim=1, keepdim=True), torch.nn.functional.normalize(xg[:, 3:], dim=1)], 1).to(dev)
+    xorders = np.stack([np.random.default_rng(s).permutation(nx) for s in range(5)])
+    for name, cloud in (("xie_ordered_propagation_10k_points_5_orders", xpc), ("xie_ordered_propagation_10k_points_5_orders_f64", xpc.double())):
+        t = timed(lambda: fu.xie_propagation_points_in_order(cloud, 0.1, xorders, diffuse=True), 10)
+        out[name] = {"ms": t * 1e3, "points": nx, "orders": 5, "us_per_step": t * 1e6 / nx,
+                     "dtype": "f64" if cloud.dtype == torch.float64 else "f32", "diffuse": True}
+    del xpc
     # the same two calls with HOST tensors in and out (the reference's functions take either): H2D + D2H of the cloud
     # over PCIe inside the timed call.  Never the headline value (inputs resident in HBM there) - DESIGN.md section 5.
     host = pts_sorted.cpu()       # oriented in place call after call (a torch CPU clone of 2.4 MB inside the timed loop costs

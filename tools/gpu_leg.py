@@ -121,9 +121,20 @@ elif leg in ("xie_order", "xie_order_f64"):
     esz = 8 if f64 else 4
     meta.update(anchor="xie_pairs_kernel", what=f"xie_propagation_points_in_order(diffuse), N = {n}, 5 orders, {'float64' if f64 else 'float32'}")
     K("xie_pairs_kernel", float(n) * n * esz, "bytes", "hbm", 1, "N x N matrix written once")
-    K("xie_order", n, "steps", "latency", 0, "one persistent workgroup per order; a step reads one matrix row")
+    K("xie_block_rows_kernel", 256.0 * n * esz * 5, "bytes", "hbm", 1, "row sums of one 256-step block: 256 matrix rows per order, 5 orders")
+    K("xie_block_solve_kernel", 256, "steps", "latency", 0, "the 256 dependent steps of a block: one wavefront per order")
     K("xie_rowdots_kernel", float(n) * n * esz, "bytes", "hbm", 1, "the diffuse pass: one pass over the matrix for all orders")
-    reps = 4
+    reps = 8
+elif leg == "xie_knn":
+    gen = torch.Generator().manual_seed(5)
+    n = 10000
+    x = torch.randn(n, 6, generator=gen)
+    pc = torch.cat([0.4 * x[:, :3] / x[:, :3].norm(dim=1, keepdim=True), torch.nn.functional.normalize(x[:, 3:], dim=1)], 1).to(dev)
+    call = lambda: fu.xie_intersaction(pc, pc, 0.1, 20, 3)
+    meta.update(anchor="xie_knn_kernel", what=f"xie_intersaction with knn_mask = 20, N = {n} (selection + masked matrix)")
+    K("xie_knn_kernel", n, "sources", "latency", 0, "k-th nearest target of every source: one wavefront per source over all N targets")
+    K("xie_pairs_kernel", float(n) * n * 4, "bytes", "hbm", 1, "masked N x N matrix written once")
+    reps = 10
 elif leg == "prep_partition":
     g = np.load(os.path.join(gdir, "G15_boxunion_config3.npz"))
     cloud = torch.from_numpy(g["pc"]).to(dev)

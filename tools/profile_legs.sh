@@ -3,7 +3,7 @@
 # final tree (profiles/SUMMARY_<round>.md, tools/make_summary.py):   tools/profile_legs.sh r05 [leg ...]
 set +e
 RND=${1:-r05}; shift
-LEGS=${@:-"config4_driver config3_reps config2_fandisk allpairs_100k config5_reference_field potential_lattice config1_points config1_points_f64 config4_driver_f64 config2_fandisk_f64 allpairs_100k_f64 config5_reference_field_f64 potential_lattice_f64 xie_order xie_order_f64 prep_partition"}
+LEGS=${@:-"config4_driver config3_reps config2_fandisk allpairs_100k config5_reference_field potential_lattice config1_points config1_points_f64 config4_driver_f64 config2_fandisk_f64 allpairs_100k_f64 config5_reference_field_f64 potential_lattice_f64 xie_order xie_order_f64 xie_knn prep_partition"}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_${RND}_legs
