@@ -10,7 +10,8 @@ no patch, ragged last tiles), random eps;
   * field_grad on ragged shapes against the oracle,
   * every 40th case one of the heavier kinds: field_grad / reference_field at 4 10^8 .. 2.7 10^9 pairs (scalar kernel, far
     launches, source split), the patch driver against the oracle's driver (visit order, normals), potential on ragged
-    shapes, the per-point driver in both forms.
+    shapes, the per-point driver in both forms, the blocked xie ordered propagation against the row-per-step kernels (with / without a
+    kNN mask and a non-permutation row).
 Prints one line per failure and a summary; exit code 1 on any failure.
 
     python tools/gpu_fuzz.py [seconds] [seed]
@@ -76,7 +77,7 @@ def run(budget=180.0, seed=0):
             print(f"  ... {cases} cases, {len(fails)} failures", flush=True)
             t_note = time.time() + 60.0
         cases += 1
-        kind = cases % 3 if cases % 40 else 3 + (cases // 40) % 4      # every 40th case: one of the heavier kinds
+        kind = cases % 3 if cases % 40 else 3 + (cases // 40) % 5      # every 40th case: one of the heavier kinds
         try:
             if kind == 0:                                    # patch slabs
                 sizes = []
@@ -245,6 +246,35 @@ def run(budget=180.0, seed=0):
                     outs.append((b.cpu(), fu.last_trace("points")["order"].copy()))
                 if not (torch.equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])):
                     fails.append(f"case {cases}: the two per-point forms disagree (N={N})")
+            elif kind == 7:                                  # xie: blocked ordered propagation against the row-per-step kernels, kNN
+                N, R = int(rng.integers(512, 3000)), int(rng.integers(1, 7))
+                f64 = bool(rng.random() < 0.4)
+                pc = cloud(N).to(dev)
+                pc = pc.double() if f64 else pc
+                lib = _lib.require_device()
+                knn = int(rng.integers(1, 80)) if rng.random() < 0.5 else -1
+                M = fu.xie_intersaction(pc, pc, 0.1, knn, 3).contiguous()
+                orders = np.stack([rng.permutation(N) for _ in range(R)]).astype(np.int64)
+                if rng.random() < 0.3:                       # one row that is not a permutation
+                    orders[0, N // 2] = orders[0, N // 3]
+                ot = torch.from_numpy(orders).to(dev)
+                w1, i1 = torch.empty((R, N), dtype=M.dtype, device=dev), torch.empty((R, N), dtype=M.dtype, device=dev)
+                w2, i2 = torch.empty_like(w1), torch.empty_like(i1)
+                nb = lib.dnp_xie_order_workspace_bytes(N, R, 8 if f64 else 4)
+                ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+                rc1 = (lib.dnp_xie_order_f64 if f64 else lib.dnp_xie_order_f32)(_lib.ptr(M), N, _lib.ptr(ot), R, _lib.ptr(w1), _lib.ptr(i1), _lib.current_stream())
+                rc2 = (lib.dnp_xie_order_blocked_f64 if f64 else lib.dnp_xie_order_blocked_f32)(_lib.ptr(M), N, _lib.ptr(ot), R, _lib.ptr(w2), _lib.ptr(i2),
+                                                                                               _lib.ptr(ws), nb, _lib.current_stream())
+                if rc1 or rc2:
+                    fails.append(f"case {cases}: xie order rc {rc1} / {rc2}")
+                elif not torch.equal(w1, w2):
+                    # a sign may differ only where the sum itself is rounding noise of its terms
+                    bad = (w1 != w2)
+                    mag = (M.abs().double() @ torch.ones(N, dtype=torch.float64, device=dev))
+                    r_, c_ = torch.nonzero(bad, as_tuple=True)
+                    worst = float((i1[bad].abs().double() / mag[c_]).max())
+                    if worst > 1e-12:
+                        fails.append(f"case {cases}: blocked xie order signs differ (N={N}, R={R}, f64={f64}, knn={knn}, {int(bad.sum())} entries, |inter|/sum|M| up to {worst:.2e})")
         except Exception as exc:                             # a library error is a failure too
             fails.append(f"case {cases} (kind {kind}): {type(exc).__name__}: {exc}")
         if len(fails) > 20:
