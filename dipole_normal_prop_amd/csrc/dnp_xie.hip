@@ -64,18 +64,26 @@ __device__ inline double ieee_sqrt(double x) { return __builtin_sqrt(x); }
 // 1e10] takes the compiler's division); a DENORMAL numerator or quotient - a coordinate difference or a normal component
 // below 1e-38, which fp32 coordinates in the unit box cannot produce (their differences are 0 or >= 2^-25 apart) - skips
 // div_scale / div_fixup here and may round differently from a / b: the bit-for-bit statement is for normal-range operands.
-// fp64 keeps the compiler's division (its expansion differs; that form is not timed).
+// fp64: the same idea on the compiler's fp64 expansion (two Newton steps, one residual correction), guard |R| in [1e-100, 1e100].
 #ifndef DNP_XIE_IEEE_DIV
 #define DNP_XIE_IEEE_DIV 0
 #endif
 template <typename F>
 struct Recip {
-    static constexpr bool kShared = sizeof(F) == 4 && !DNP_XIE_IEEE_DIV;
+    static constexpr bool kShared = !DNP_XIE_IEEE_DIV;
     F b, r;
     __device__ explicit Recip(F den) : b(den), r(F(0)) {
         if constexpr (sizeof(F) == 4 && !DNP_XIE_IEEE_DIV) {
             const float r0 = __builtin_amdgcn_rcpf(den);
             r = __builtin_fmaf(__builtin_fmaf(-den, r0, 1.0f), r0, r0);
+        } else if constexpr (sizeof(F) == 8 && !DNP_XIE_IEEE_DIV) {
+            // fp64 (round 5): hipcc's a / b is div_scale x 2, v_rcp_f64, TWO Newton steps on the reciprocal, q0 = a r, one residual
+            // correction in div_fmas, div_fixup - 13 instructions and a transcendental per quotient; the refined reciprocal once
+            // per denominator leaves three instructions per quotient, the same bits for normal-range operands (checked against a
+            // -DDNP_XIE_IEEE_DIV=1 build on 10^8 pairs, tools/gpu_xie_time.py)
+            const double r0 = __builtin_amdgcn_rcp(den);
+            const double r1 = __builtin_fma(r0, __builtin_fma(-den, r0, 1.0), r0);
+            r = __builtin_fma(r1, __builtin_fma(-den, r1, 1.0), r1);
         }
     }
     __device__ F divide(F a) const {
@@ -84,6 +92,9 @@ struct Recip {
             q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
             q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
             return q;
+        } else if constexpr (sizeof(F) == 8 && !DNP_XIE_IEEE_DIV) {
+            const double q = a * r;
+            return __builtin_fma(__builtin_fma(-b, q, a), r, q);
         } else {
             return a / b;
         }
@@ -118,7 +129,8 @@ __global__ __launch_bounds__(kXieBlock) void xie_pairs_kernel(const XieArgs<F> a
         const F n3 = nrm * nrm * nrm;
         const bool coincident = nrm == F(0);
         F ux, uy, uz, d, fx, fy, fz;
-        if (Recip<F>::kShared && !(nrm >= F(1e-10) && nrm <= F(1e10)) && !coincident) {
+        constexpr F kLoR = sizeof(F) == 4 ? F(1e-10) : F(1e-100), kHiR = sizeof(F) == 4 ? F(1e10) : F(1e100);
+        if (Recip<F>::kShared && !(nrm >= kLoR && nrm <= kHiR) && !coincident) {
             // |R| at an exponent extreme (never on a cloud in the unit box): |R|^3 may be denormal or overflow, where the
             // compiler's division rescales its operands - take that division itself
             ux = rx / nrm; uy = ry / nrm; uz = rz / nrm;

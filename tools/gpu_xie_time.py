@@ -23,6 +23,7 @@ if not os.path.exists(IEEE):
     build.build(extra_flags=["-DDNP_XIE_IEEE_DIV=1"], out=IEEE, verbose=False)
 ieee = ctypes.CDLL(IEEE)
 ieee.dnp_xie_pairs_f32.restype, ieee.dnp_xie_pairs_f32.argtypes = _lib.SIGNATURES["dnp_xie_pairs_f32"]
+ieee.dnp_xie_pairs_f64.restype, ieee.dnp_xie_pairs_f64.argtypes = _lib.SIGNATURES["dnp_xie_pairs_f64"]
 PLAIN = os.path.join(ROOT, "tools", "bin", "libdnp_xie_plain.so")
 if not os.path.exists(PLAIN):
     from dipole_normal_prop_amd import build
@@ -68,6 +69,18 @@ for n in (4000, 10000, 16000):
         print(f"N={n:6d} xie {label} with the compiler's division per quotient: {mn_i * 1e3:8.1f} us min; results bit-identical: {same}")
         print(f"N={n:6d} xie {label} C ABI: {med * 1e3:8.1f} us median / {mn * 1e3:8.1f} min   {gb / mn * 1e3:7.1f} GB/s written "
               f"({gb * 1e3:.0f} MB), {n * n / mn / 1e6:.1f} Gpairs/s")
+    if n <= 10000:      # fp64: the shared refined reciprocal (round 5) against the compiler's division, clustered cloud included
+        for cname, c64 in (("sphere", pc.double()), ("clustered", torch.cat([pc[:n // 2].double() * 1e-3, pc[n // 2:].double()]).contiguous())):
+            for vec, label in ((0, "matrix"), (1, "field ")):
+                if vec and n > 4000:
+                    continue
+                out = torch.empty((n, n, 3) if vec else (n, n), dtype=torch.float64, device=dev)
+                ref = torch.empty_like(out)
+                med, mn = timed(lambda: lib.dnp_xie_pairs_f64(_lib.ptr(c64), n, 6, _lib.ptr(c64), n, 6, 3.0, vec, _lib.ptr(out), stream), reps=10)
+                med_i, mn_i = timed(lambda: ieee.dnp_xie_pairs_f64(_lib.ptr(c64), n, 6, _lib.ptr(c64), n, 6, 3.0, vec, _lib.ptr(ref), stream), reps=10)
+                print(f"N={n:6d} fp64 xie {label} ({cname}): {mn * 1e3:8.1f} us min | compiler's division per quotient {mn_i * 1e3:8.1f} us; "
+                      f"results bit-identical: {bool(torch.equal(out, ref))}", flush=True)
+                del out, ref
     med, mn = timed(lambda: fu.xie_intersaction(pc, pc, 0.1, -1, 3), reps=10)
     print(f"N={n:6d} fu.xie_intersaction (allocates the matrix): {med * 1e3:8.1f} us median / {mn * 1e3:8.1f} min")
     if n <= 10000:
