@@ -85,3 +85,33 @@ def test_exchange_hand_off_is_write_through_stores_then_a_wait_then_the_ticket()
         inv = [i for i, ln in enumerate(after) if ln.startswith("buffer_inv") and "sc1" in ln]
         loads = [i for i, ln in enumerate(after) if ln.startswith("global_load_dwordx2") and "sc1" in ln]
         assert inv and loads and min(inv) < min(loads), (name, inv[:2], loads[:2])
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not found")
+def test_blocked_xie_solve_loop_waits_for_its_oldest_column_only():
+    """The solve kernel of the blocked ordered propagation keeps 8 corner columns in flight ACROSS the back edge of its step loop:
+    the loads are hand-issued (inline asm) and every step waits with s_waitcnt vmcnt(7) (fp64: two loads per column, vmcnt(14)) -
+    compiler-visible loads had made the loop header drain everything (vmcnt(0)) every 8 steps, 250 cycles per step instead of
+    ~130.  Pinned here: inside the loop, one such wait and one column load per step, and no full drain."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_resources.py"), "dnp_xie.hip"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = open("/tmp/isa/dnp_xie.hip.s").read()
+    for mangled, younger, loads_per_step in (("_ZN3dnp22xie_block_solve_kernelIfEE", 7, 1), ("_ZN3dnp22xie_block_solve_kernelIdEE", 14, 2)):
+        start = re.search(r"^" + mangled + r"\w*:", text, flags=re.M)
+        assert start, mangled
+        body = text[start.start():text.index(".end_amdhsa_kernel", start.start())]
+        lines = [ln.split(";")[0].strip() for ln in body.splitlines()]
+        lines = [ln for ln in lines if ln]
+        # the step loop = from the first loop label that is branched back to, to that branch
+        labels = {ln[:-1]: i for i, ln in enumerate(lines) if ln.endswith(":") and ln.startswith(".LBB")}
+        back = [(labels[ln.split()[-1]], i) for i, ln in enumerate(lines)
+                if ln.startswith("s_cbranch") and ln.split()[-1] in labels and labels[ln.split()[-1]] < i]
+        # the unrolled step loop: the shortest backward branch whose body issues the 8 columns of an iteration
+        cands = [be for be in back if sum(ln.startswith("global_load_dwordx4") for ln in lines[be[0]:be[1]]) >= 8 * loads_per_step]
+        assert cands, (mangled, back)
+        lo, hi = min(cands, key=lambda be: be[1] - be[0])
+        loop = lines[lo:hi]
+        waits = [ln for ln in loop if ln.startswith("s_waitcnt") and "vmcnt" in ln]
+        assert len(waits) == 8 and all(f"vmcnt({younger})" in ln for ln in waits), (mangled, waits)
+        assert sum(ln.startswith("global_load_dwordx4") for ln in loop) == 8 * loads_per_step, mangled
