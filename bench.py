@@ -326,7 +326,8 @@ def main():
         fb = fu._balanced_blocks(sizes, fake)
         p_lo, p_hi = int(fb[0]), int(fb[1])
     my_pairs = float((sizes[p_lo:p_hi] * (N_POINTS - sizes[p_lo:p_hi])).sum())
-    split = fu._pick_source_split(sizes[p_lo:p_hi], N_POINTS)     # the drivers' rule: short launches split their items
+    # the drivers' launch plan (patch_drivers._launch_plan): longest patches first, a split tail when even the shortest are long
+    order, split = fu._launch_plan(sizes[p_lo:p_hi], N_POINTS, dev)
     # The headline step gathers in the launch stream's order (what the product's driver does).  At N > 1 over RCCL a second
     # timed loop overlaps the all-gather with the next step's pair kernel (BENCH_NO_PIPELINED=1 skips it; BENCH_PIPELINED=1
     # forces it on other backends / one rank, where gather_rows_async falls back to the in-order form).
@@ -343,9 +344,9 @@ def main():
             marks[0].record()
         if tiles.fused:              # what the drivers do (patch_drivers._slabs_and_rows), opened up for the event marks
             w_part = torch.empty((p_hi - p_lo, tiles.n_tiles, tiles.slots), dtype=torch.float64, device=dev)
-            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part, split)
+            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part, split, order)
         else:
-            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, None, split)
+            dE = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, None, split, order)
         if marks is not None:
             marks[1].record()
         if tiles.fused:
@@ -412,7 +413,7 @@ def main():
         deadline.phase = "precheck (first collectives)"
         torch.cuda.synchronize()
         w_part0 = torch.empty((p_hi - p_lo, tiles.n_tiles, tiles.slots), dtype=torch.float64, device=dev) if tiles.fused else None
-        dE0 = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part0, split)
+        dE0 = fu._patch_slabs(pts, off, idx, point_patch, p_lo, p_hi, 1e-5, boxes, tiles.boxes, w_part0, split, order)
         if tiles.fused:
             W_local = torch.empty((p_hi - p_lo, N_PATCHES), dtype=torch.float64, device=dev)
             fu._lib.check(fu._lib.require_device().dnp_interactions_from_tiles(
@@ -528,6 +529,7 @@ def main():
                 "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VALU_PEAK_TFLOPS,
                 "traffic": None, "launch_ms": k_ms, "launch_ms_median": k_med, "launch_ms_min": k_min,
                 "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": launch_pairs, "source_split": split,
+                "launch_order": "longest patch first" if order is not None else "patch order",
                 "timed": f"HIP events around dnp_patch_fields_tiled_f32 (one pair_kernel_scalar launch) on torch's current "
                          f"stream, recorded inside the {args.steps} timed steps; achieved = 33 flop x pairs_per_launch / "
                          f"mean launch_ms",

@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DNP_LIB", os.path.join(_HERE, "libdnp.so"))
 
-ABI_VERSION = 502          # DNP_VERSION of include/dnp.h this binding matches (0.5.0: fp64 patch-driver entry points)
+ABI_VERSION = 503          # DNP_VERSION of include/dnp.h this binding matches (0.5.0: fp64 patch-driver entry points)
 
 _c_i64 = ctypes.c_int64
 _c_p = ctypes.c_void_p
@@ -46,6 +46,10 @@ SIGNATURES = {
                                                   ctypes.c_float, _c_p, _c_p, ctypes.c_int, ctypes.c_int, _c_p, _c_sz, _c_p]),
     "dnp_patch_fields_tiled_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64,
                                                   ctypes.c_double, _c_p, _c_p, ctypes.c_int, _c_p]),
+    "dnp_patch_fields_ordered_f32": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p,
+                                                    ctypes.c_float, _c_p, _c_p, ctypes.c_int, ctypes.c_int, _c_p, _c_sz, _c_p]),
+    "dnp_patch_fields_ordered_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p,
+                                                    ctypes.c_double, _c_p, _c_p, ctypes.c_int, _c_p]),
     "dnp_patch_boxes_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p]),
     "dnp_tile_boxes_f64": (ctypes.c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
     "dnp_patch_exchange_bytes": (_c_sz, [_c_i64, _c_i64]),

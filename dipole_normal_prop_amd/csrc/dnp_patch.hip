@@ -294,11 +294,11 @@ int dnp_exchange_init(void* exchange, size_t bytes, void* stream) {
     return DNP_OK;
 }
 
-int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
-                               const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
-                               const float* patch_box, const float* tile_box, int64_t p_begin, int64_t p_end, float eps,
-                               float* dE, double* w_part, int w_slots, int source_split, void* exchange, size_t exchange_bytes,
-                               void* stream) {
+static int patch_fields_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
+                            const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
+                            const float* patch_box, const float* tile_box, int64_t p_begin, int64_t p_end, float eps,
+                            float* dE, double* w_part, int w_slots, int source_split, void* exchange, size_t exchange_bytes,
+                            const int32_t* patch_order, void* stream) {
     clear_error();
     DNP_REQUIRE(!w_part || w_slots == 2 || w_slots == 3, "w_slots=%d (2 or 3 group slots per tile)", w_slots);
     DNP_REQUIRE(source_split == 1 || (source_split < 0 && source_split >= -65535),
@@ -315,6 +315,7 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
                 "w_part needs the patch-sorted layout (patch_idx == NULL), eps >= 1e-30 and both box tables");
     const int64_t t_tiles = ceil_div(N, (int64_t)kBlock * kPatchKT);
     const int64_t K = p_end - p_begin;
+    DNP_REQUIRE(!patch_order || (scalar_path && K <= 65535), "patch_order needs the patch-sorted layout, eps > 0 and at most 65535 patches");
     // grid.y is limited to 65535 workgroups: walk the patch range in slices
     for (int64_t k0 = 0; k0 < K; k0 += 65535) {
         const int64_t kn = (K - k0 < 65535) ? (K - k0) : 65535;
@@ -323,6 +324,7 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
         pa.tgt = pts; pa.ld_tgt = ld_pts; pa.tgt_idx = nullptr; pa.T = N;
         pa.chunk_off_dev = patch_off; pa.chunk_base = p_begin + k0; pa.tgt_group = point_patch;
         pa.eps = eps; pa.partial = dE + k0 * N * 3;
+        pa.chunk_perm = patch_order;
         pa.far_d2 = (float)far_threshold_d2((double)eps);
 #ifdef DNP_FAR_D2   // timing experiments only: force the far test (1e30f = never far, -1.f = always far)
         pa.far_d2 = DNP_FAR_D2;
@@ -334,7 +336,7 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
             pa.bnd.n_chunk_off = P + 1; pa.bnd.n_chunk_box = patch_box ? P : 0; pa.bnd.n_tile_box = tile_box ? n_tiles_b : 0;
             pa.bnd.n_tgt_group = N; pa.bnd.n_w_part = w_part ? kn * n_tiles_b * w_slots : 0; pa.bnd.n_partial = kn * N * 3;
             pa.bnd.n_xch_items = exchange ? (int64_t)(exchange_bytes / (size_t)xch_item_bytes(4, kPatchScalarKT, 3)) : 0;
-            pa.bnd.n_src_rows = N; pa.bnd.err = bounds_err_buffer();
+            pa.bnd.n_src_rows = N; pa.bnd.n_chunk_perm = patch_order ? kn : 0; pa.bnd.err = bounds_err_buffer();
         }
 #endif
         if (scalar_path) {
@@ -408,6 +410,23 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
     return DNP_OK;
 }
 
+int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
+                               const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
+                               const float* patch_box, const float* tile_box, int64_t p_begin, int64_t p_end, float eps,
+                               float* dE, double* w_part, int w_slots, int source_split, void* exchange, size_t exchange_bytes,
+                               void* stream) {
+    return patch_fields_f32(pts, N, ld_pts, patch_off, patch_idx, P, point_patch, patch_box, tile_box, p_begin, p_end, eps, dE, w_part,
+                            w_slots, source_split, exchange, exchange_bytes, nullptr, stream);
+}
+
+int dnp_patch_fields_ordered_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off, int64_t P,
+                                 const int64_t* point_patch, const float* patch_box, const float* tile_box, int64_t p_begin,
+                                 int64_t p_end, const int32_t* patch_order, float eps, float* dE, double* w_part, int w_slots,
+                                 int source_split, void* exchange, size_t exchange_bytes, void* stream) {
+    return patch_fields_f32(pts, N, ld_pts, patch_off, nullptr, P, point_patch, patch_box, tile_box, p_begin, p_end, eps, dE, w_part,
+                            w_slots, source_split, exchange, exchange_bytes, patch_order, stream);
+}
+
 // ---- the same slabs for a FLOAT64 cloud (round 5): the reference computes in the dtype it is handed (field_utils.py:96-109) and
 // its socket path hands it float64 (util.py:71-77), so a float64 cloud's patch fields, interaction sums and diffuse field
 // are evaluated in double: the scalar-unit kernel at KT = 2 on the patch-sorted layout (two-wavefront workgroups, XCD-aware
@@ -420,10 +439,11 @@ int dnp_patch_fields_tiled_f32(const float* pts, int64_t N, int64_t ld_pts, cons
 constexpr int kPatchScalarKT64 = DNP_KT64;
 static_assert(kPatchScalarKT64 == kPatchScalarKT, "w_part tiles of both precisions are dnp_patch_tile_rows() rows");
 
-int dnp_patch_fields_tiled_f64(const double* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
-                               const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
-                               const double* patch_box, const double* tile_box,
-                               int64_t p_begin, int64_t p_end, double eps, double* dE, double* w_part, int w_slots, void* stream) {
+static int patch_fields_f64(const double* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
+                            const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
+                            const double* patch_box, const double* tile_box,
+                            int64_t p_begin, int64_t p_end, double eps, double* dE, double* w_part, int w_slots,
+                            const int32_t* patch_order, void* stream) {
     clear_error();
     DNP_REQUIRE(!w_part || w_slots == 2 || w_slots == 3, "w_slots=%d (2 or 3 group slots per tile)", w_slots);
     DNP_REQUIRE(N >= 0 && P >= 0, "negative size");
@@ -436,6 +456,7 @@ int dnp_patch_fields_tiled_f64(const double* pts, int64_t N, int64_t ld_pts, con
     DNP_REQUIRE(!w_part || scalar_path, "w_part needs the patch-sorted layout (patch_idx == NULL) and eps > 0");
     const int64_t K = p_end - p_begin;
     const int64_t n_tiles = ceil_div(N, (int64_t)64 * kPatchScalarKT64);
+    DNP_REQUIRE(!patch_order || (scalar_path && K <= 65535), "patch_order needs the patch-sorted layout, eps > 0 and at most 65535 patches");
     for (int64_t k0 = 0; k0 < K; k0 += 65535) {
         const int64_t kn = (K - k0 < 65535) ? (K - k0) : 65535;
         PairArgs<double, double> pa{};
@@ -443,6 +464,7 @@ int dnp_patch_fields_tiled_f64(const double* pts, int64_t N, int64_t ld_pts, con
         pa.tgt = pts; pa.ld_tgt = ld_pts; pa.tgt_idx = nullptr; pa.T = N;
         pa.chunk_off_dev = patch_off; pa.chunk_base = p_begin + k0; pa.tgt_group = point_patch;
         pa.eps = eps; pa.partial = dE + k0 * N * 3;
+        pa.chunk_perm = patch_order;
         const bool tabled = scalar_path && patch_box && tile_box && far_threshold_d2(eps, kFarRatio64) > 0.0;
         pa.far_d2 = tabled ? far_threshold_d2(eps, kFarRatio64) : 0.0;
         pa.chunk_box = tabled ? patch_box : nullptr;
@@ -453,7 +475,7 @@ int dnp_patch_fields_tiled_f64(const double* pts, int64_t N, int64_t ld_pts, con
         pa.bnd = PairBounds{};
         pa.bnd.n_chunk_off = P + 1; pa.bnd.n_tgt_group = N; pa.bnd.n_w_part = w_part ? kn * n_tiles * w_slots : 0;
         pa.bnd.n_chunk_box = tabled ? P : 0; pa.bnd.n_tile_box = tabled ? n_tiles : 0;
-        pa.bnd.n_partial = kn * N * 3; pa.bnd.n_src_rows = N; pa.bnd.err = bounds_err_buffer();
+        pa.bnd.n_partial = kn * N * 3; pa.bnd.n_src_rows = N; pa.bnd.n_chunk_perm = patch_order ? kn : 0; pa.bnd.err = bounds_err_buffer();
 #endif
         if (scalar_path) {
             const dim3 sgrid((unsigned)ceil_div(N, (int64_t)kTabledWaves * 64 * kPatchScalarKT64), (unsigned)kn);
@@ -476,6 +498,22 @@ int dnp_patch_fields_tiled_f64(const double* pts, int64_t N, int64_t ld_pts, con
         DNP_CHECK_HIP(hipGetLastError());
     }
     return DNP_OK;
+}
+
+int dnp_patch_fields_tiled_f64(const double* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off,
+                               const int64_t* patch_idx, int64_t P, const int64_t* point_patch,
+                               const double* patch_box, const double* tile_box,
+                               int64_t p_begin, int64_t p_end, double eps, double* dE, double* w_part, int w_slots, void* stream) {
+    return patch_fields_f64(pts, N, ld_pts, patch_off, patch_idx, P, point_patch, patch_box, tile_box, p_begin, p_end, eps, dE, w_part,
+                            w_slots, nullptr, stream);
+}
+
+int dnp_patch_fields_ordered_f64(const double* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off, int64_t P,
+                                 const int64_t* point_patch, const double* patch_box, const double* tile_box, int64_t p_begin,
+                                 int64_t p_end, const int32_t* patch_order, double eps, double* dE, double* w_part, int w_slots,
+                                 void* stream) {
+    return patch_fields_f64(pts, N, ld_pts, patch_off, nullptr, P, point_patch, patch_box, tile_box, p_begin, p_end, eps, dE, w_part,
+                            w_slots, patch_order, stream);
 }
 
 int dnp_interactions_f32(const float* dE, int64_t K, int64_t N, const float* pts, int64_t ld_pts,

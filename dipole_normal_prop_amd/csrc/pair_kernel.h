@@ -153,6 +153,7 @@ struct PairBounds {
     int64_t n_partial;       // elements of partial
     int64_t n_xch_items;     // records of the exchange buffer
     int64_t n_src_rows;      // rows of src
+    int64_t n_chunk_perm;    // entries of chunk_perm
     unsigned int* err;       // [16] counters: [0..7] out-of-bounds accesses by table (kBnd*), [8] tiles that break WPART's precondition
 };
 enum { kBndChunkOff = 0, kBndChunkBox = 1, kBndTileBox = 2, kBndTgtGroup = 3, kBndWPart = 4, kBndPartial = 5, kBndXch = 6, kBndSrc = 7,
@@ -199,6 +200,10 @@ struct PairArgs {
     // their counters in the same words: zero before the first launch, left zero by every launch.
     unsigned int* xch_ticket;  // = the buffer; item i's counter is xch_ticket[i * xch_item_bytes / 4]
     double* xch_terms;         // = the buffer + 128 bytes; item i's terms start at xch_terms[i * xch_item_bytes / 8]
+    // scalar kernel: launch row -> chunk of the launch (a permutation of 0..n-1), or nullptr = identity.  Workgroups are
+    // dispatched in launch order, so the LAST rows decide how a launch ends: the drivers put the longest patches first
+    // (longest-processing-time-first; round 5, profiles/r05_tail_sweep.txt).  Slabs, partials and boxes stay indexed by chunk.
+    const int32_t* chunk_perm;
 #ifdef DNP_BOUNDS
     PairBounds bnd;
 #endif
@@ -765,6 +770,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel_scalar(const PairArgs<
     } else {
         if (DNP_XCD_MAP && bx < (gridDim.x & ~7u)) bx = (bx & ~7u) | ((bx + blockIdx.y * gridDim.x) & 7u);
     }
+    if (a.chunk_perm) chunk = a.chunk_perm[DNP_BND(chunk, n_chunk_perm, kBndChunkOff)];     // launch row -> chunk
     int64_t s_begin, s_end;
     if (a.chunk_off_dev) {
         s_begin = a.chunk_off_dev[DNP_BND(a.chunk_base + chunk, n_chunk_off, kBndChunkOff)];

@@ -230,6 +230,6 @@ from .patch_drivers import (_Batched, _BatchedWork, _TileTables, _balanced_block
                             _batched_patch_propagation, _combine, _combine_signed, _csr, _diffuse_sign_pass, _disjoint, _exchange,
                             _exchange_drop, _finish_batched, _finish_patch_driver, _flattest_patch, _flip_by_listing,
                             _free_device_bytes, _greedy_on_device, _interaction_rows, _listed_patches, _listing_ids, _patch_boxes,
-                            _patch_slabs, _pick_source_split, _point_patch_ids, _prepare_work, _sequential_patch_propagation,
+                            _launch_plan, _patch_slabs, _pick_source_split, _point_patch_ids, _prepare_work, _sequential_patch_propagation,
                             _slabs_and_rows, _start_tensor, _store_normals, _tile_group_slots, _tiles_within_two_groups)
 from .point_driver import strongest_field_propagation_points, _cu_count, _points_stepwise  # noqa: F401,E402

@@ -155,24 +155,33 @@ def _exchange_drop(dev: torch.device) -> None:
 
 
 def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, eps: float, boxes=None, tile_boxes=None,
-                 w_part: Optional[torch.Tensor] = None, source_split: int = 1) -> torch.Tensor:
-    """dE[p1 - p0, N, 3]: the fields of patches p0..p1 on every point (dnp_patch_fields_tiled_f32).  boxes / tile_boxes:
-    the per-cloud box tables of the far-field test (_patch_boxes, _tile_boxes); w_part: receives the per-tile
+                 w_part: Optional[torch.Tensor] = None, source_split: int = 1, order: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dE[p1 - p0, N, 3]: the fields of patches p0..p1 on every point (dnp_patch_fields_tiled_f32 / _ordered_f32).  boxes /
+    tile_boxes: the per-cloud box tables of the far-field test (_patch_boxes, _tile_boxes); w_part: receives the per-tile
     interaction partials [p1 - p0, n_tiles, 2 or 3] (see _TileTables; the last dimension = the group slots per tile).
-    source_split = -k: the last k patches of the launch as split items whose run
-    terms travel through the exchange buffer (needs both box tables; without them the launch is the plain one)."""
+    source_split = -k: the last k ROWS of the launch as split items whose run terms travel through the exchange buffer (needs
+    both box tables; without them the launch is the plain one).  order (device int32 [p1 - p0], patch-sorted layout only): the
+    patch, relative to p0, that launch row i evaluates - _launch_plan puts the longest patches first; slab k stays patch p0 + k."""
     lib = _lib.require_device()
     N = work.shape[0]
     dE = torch.empty((p1 - p0, N, 3), dtype=work.dtype, device=work.device)
+    ordered = order is not None and idx is None and eps > 0 and p1 - p0 <= 65535
     if work.dtype == torch.float64:
         # a float64 cloud: double-precision slabs (the fp64 far chain when both box tables are given; no split tail)
         both = boxes is not None and tile_boxes is not None
         with _on_device(work.device):
-            rc = lib.dnp_patch_fields_tiled_f64(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
-                                                off.shape[0] - 1, _lib.ptr(point_patch), _lib.ptr(boxes if both else None),
-                                                _lib.ptr(tile_boxes if both else None), p0, p1, float(eps), _lib.ptr(dE),
-                                                _lib.ptr(w_part), 2 if w_part is None else int(w_part.shape[-1]),
-                                                _lib.current_stream())
+            if ordered:
+                rc = lib.dnp_patch_fields_ordered_f64(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), off.shape[0] - 1,
+                                                      _lib.ptr(point_patch), _lib.ptr(boxes if both else None),
+                                                      _lib.ptr(tile_boxes if both else None), p0, p1, _lib.ptr(order), float(eps),
+                                                      _lib.ptr(dE), _lib.ptr(w_part), 2 if w_part is None else int(w_part.shape[-1]),
+                                                      _lib.current_stream())
+            else:
+                rc = lib.dnp_patch_fields_tiled_f64(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
+                                                    off.shape[0] - 1, _lib.ptr(point_patch), _lib.ptr(boxes if both else None),
+                                                    _lib.ptr(tile_boxes if both else None), p0, p1, float(eps), _lib.ptr(dE),
+                                                    _lib.ptr(w_part), 2 if w_part is None else int(w_part.shape[-1]),
+                                                    _lib.current_stream())
         _lib.check(rc)
         return dE
     xch, xch_bytes = None, 0
@@ -180,11 +189,18 @@ def _patch_slabs(work: torch.Tensor, off, idx, point_patch, p0: int, p1: int, ep
         xch_bytes = int(lib.dnp_patch_exchange_bytes(N, min(-source_split, p1 - p0)))
         xch = _exchange(xch_bytes, work.device)
     with _on_device(work.device):
-        rc = lib.dnp_patch_fields_tiled_f32(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
-                                            off.shape[0] - 1, _lib.ptr(point_patch), _lib.ptr(boxes), _lib.ptr(tile_boxes),
-                                            p0, p1, float(eps), _lib.ptr(dE), _lib.ptr(w_part),
-                                            2 if w_part is None else int(w_part.shape[-1]), int(source_split),
-                                            _lib.ptr(xch), xch_bytes, _lib.current_stream())
+        if ordered:
+            rc = lib.dnp_patch_fields_ordered_f32(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), off.shape[0] - 1,
+                                                  _lib.ptr(point_patch), _lib.ptr(boxes), _lib.ptr(tile_boxes), p0, p1, _lib.ptr(order),
+                                                  float(eps), _lib.ptr(dE), _lib.ptr(w_part),
+                                                  2 if w_part is None else int(w_part.shape[-1]), int(source_split),
+                                                  _lib.ptr(xch), xch_bytes, _lib.current_stream())
+        else:
+            rc = lib.dnp_patch_fields_tiled_f32(_lib.ptr(work), N, work.stride(0), _lib.ptr(off), _lib.ptr(idx),
+                                                off.shape[0] - 1, _lib.ptr(point_patch), _lib.ptr(boxes), _lib.ptr(tile_boxes),
+                                                p0, p1, float(eps), _lib.ptr(dE), _lib.ptr(w_part),
+                                                2 if w_part is None else int(w_part.shape[-1]), int(source_split),
+                                                _lib.ptr(xch), xch_bytes, _lib.current_stream())
     if rc != 0 and xch is not None:
         _exchange_drop(work.device)               # its counters may not be re-armed: never reuse it
     _lib.check(rc)
@@ -265,20 +281,55 @@ TAIL_MAX_PATCHES = 8
 
 def _pick_source_split(sizes_block: np.ndarray, n_targets: int) -> int:
     """source_split for a launch over patches of these sizes: 1, or -k (the last k patches split) when the launch is below
-    TAIL_BELOW_PAIRS: k = the fewest trailing patches whose members of <= 512 points (the ones whose items become short) hold
-    TAIL_SOURCES points (TAIL_PATCHES for patches of the bench's size), at most TAIL_MAX_PATCHES; no tail when none of them
-    has 129..512 points (nothing would be split)."""
+    TAIL_BELOW_PAIRS: k = the fewest trailing patches that hold TAIL_SOURCES points, at most TAIL_MAX_PATCHES - and none of them
+    larger than 512 points: the tail ends in front of the last such patch (it would stay one wavefront per tile inside a
+    four-wavefront item; with those counted in, rank 3 of 8 on the reference's grid partition fell from 0.90 to 0.84 of ideal,
+    profiles/r05_tail_sweep.txt).  No tail when none of its patches has 129..512 points (nothing would be split)."""
     n = len(sizes_block)
     if n == 0 or float(sizes_block.sum()) * float(n_targets) >= TAIL_BELOW_PAIRS:
         return 1
     rev = np.asarray(sizes_block, dtype=np.int64)[::-1]
-    csum = np.cumsum(np.where(rev <= 512, rev, 0))
-    k = int(np.searchsorted(csum, TAIL_SOURCES, side="left")) + 1
-    k = min(k, TAIL_MAX_PATCHES, n)
+    big = np.flatnonzero(rev > 512)
+    run = int(big[0]) if big.size else n                  # trailing patches of <= 512 points
+    run = min(run, TAIL_MAX_PATCHES)
+    if run == 0:
+        return 1
+    csum = np.cumsum(rev[:run])
+    k = min(int(np.searchsorted(csum, TAIL_SOURCES, side="left")) + 1, run)
     tail = rev[:k]
-    if not bool(np.any((tail > 128) & (tail <= 512))):
+    if not bool(np.any(tail > 128)):
         return 1
     return -k
+
+
+# With the longest patches first (_launch_plan) a launch ends on its SHORTEST patches, and a split tail only pays when even those
+# are long: on the reference's grid partition and on boxunion (last patches of 100..230 points) every tail costs 1-3 % of a rank's
+# share of eight, with last patches of ~300 points (and on the bench's 343..439-point patches) it gains 1-3 % (profiles/r05_tail_sweep.txt).
+TAIL_MIN_LAST = 256
+_plan_cache = {}
+
+
+def _launch_plan(sizes_block, n_targets: int, dev, tail: bool = True):
+    """(order, source_split) of one pair-kernel launch over patches of these sizes (in patch order).  order: device int32
+    permutation, longest patch first (stable; None when the patches already come that way) - workgroups are dispatched in launch
+    order, so the shortest items drain the chip at the end (longest-processing-time-first): one rank's share of eight 0.91-0.95 of
+    ideal on the reference's grid partition where patch order gave 0.84-0.92 with the best split tail (profiles/r05_tail_sweep.txt).
+    source_split: the split tail for the last rows of THAT order, only when the shortest patch has more than TAIL_MIN_LAST points."""
+    sizes_block = np.ascontiguousarray(sizes_block, dtype=np.int64)
+    key = (sizes_block.tobytes(), int(n_targets), str(dev), bool(tail))
+    hit = _plan_cache.get(key)
+    if hit is not None:
+        return hit
+    perm = np.argsort(-sizes_block, kind="stable")
+    in_order = sizes_block[perm]
+    split = 1
+    if tail and len(in_order) and int(in_order[-1]) > TAIL_MIN_LAST:
+        split = _pick_source_split(in_order, n_targets)
+    order = None if bool(np.all(perm == np.arange(len(perm)))) else util.to_device(perm.astype(np.int32), dev)
+    if len(_plan_cache) > 256:
+        _plan_cache.clear()
+    _plan_cache[key] = (order, split)
+    return order, split
 
 
 def _slabs_and_rows(swork, off, point_patch, b0: int, b1: int, eps: float, boxes, tiles: "_TileTables", sizes=None):
@@ -287,18 +338,19 @@ def _slabs_and_rows(swork, off, point_patch, b0: int, b1: int, eps: float, boxes
     the K3 pass over the slabs."""
     P = off.shape[0] - 1
     f64 = swork.dtype == torch.float64
-    split = 1 if (sizes is None or tiles is None or boxes is None or f64) else _pick_source_split(np.asarray(sizes)[b0:b1], swork.shape[0])
+    order, split = (None, 1) if sizes is None else _launch_plan(np.asarray(sizes)[b0:b1], swork.shape[0], swork.device,
+                                                               tail=not (tiles is None or boxes is None or f64))
     if tiles is not None and tiles.fused and ((boxes is not None and eps >= 1e-30) or (f64 and eps > 0)):
         lib = _lib.require_device()
         K, N = b1 - b0, swork.shape[0]
         w_part = torch.empty((K, tiles.n_tiles, tiles.slots), dtype=torch.float64, device=swork.device)
-        dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, tiles.boxes, w_part, split)
+        dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, tiles.boxes, w_part, split, order)
         W = torch.empty((K, P), dtype=torch.float64, device=swork.device)            # (tile geometry and sums: the same in both precisions)
         with _on_device(swork.device):
             _lib.check(lib.dnp_interactions_from_tiles(_lib.ptr(w_part), tiles.slots, K, N, _lib.ptr(point_patch), _lib.ptr(off), P,
                                                        _lib.ptr(W), _lib.current_stream()))
         return dE, W
-    dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, None if tiles is None else tiles.boxes, None, split)
+    dE = _patch_slabs(swork, off, None, point_patch, b0, b1, eps, boxes, None if tiles is None else tiles.boxes, None, split, order)
     return dE, _interaction_rows(dE, swork, off, None)
 
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DNP_VERSION 502 /* 0.5.2: + dnp_xie_order_blocked_*; 0.5.1: + dnp_xie_knn_*, dnp_xie_pairs_knn_* (0.5.0: the fp64 patch-driver entry points, dnp_xie_order_f64, dnp_xie_rowdots_*) */
+#define DNP_VERSION 503 /* 0.5.3: + dnp_patch_fields_ordered_*; 0.5.2: + dnp_xie_order_blocked_*; 0.5.1: + dnp_xie_knn_*, dnp_xie_pairs_knn_* (0.5.0: the fp64 patch-driver entry points, dnp_xie_order_f64, dnp_xie_rowdots_*) */
 
 enum {
     DNP_OK = 0,
@@ -221,6 +221,24 @@ int dnp_patch_fields_tiled_f64(const double* pts, int64_t N, int64_t ld_pts,
                                const int64_t* point_patch, const double* patch_box, const double* tile_box,
                                int64_t p_begin, int64_t p_end, double eps,
                                double* dE, double* w_part, int w_slots, void* stream);
+/* The same launches on the patch-sorted layout (patch_idx == NULL, eps > 0) with a LAUNCH ORDER (round 5): patch_order[i] (device
+ * int32, a permutation of 0 .. p_end - p_begin - 1; NULL = identity; at most 65535 patches) names the patch, relative to p_begin,
+ * that launch row i evaluates.  Workgroups are dispatched in row order, so the last rows decide how the launch drains: the drivers
+ * put the LONGEST patches first (a stable sort by descending size - longest-processing-time-first).  On partitions with uneven
+ * patches that is worth more than the split tail: one rank's share of eight on the reference's grid partition of the bench sphere
+ * (patches of 100..677 points) 0.914-0.951 of ideal over the eight ranks against 0.835-0.923, on boxunion's 369 representatives'
+ * patches 0.936-0.956 against 0.91-0.94 (profiles/r05_tail_sweep.txt).  dE, w_part and the exchange contract are exactly those of
+ * dnp_patch_fields_tiled_*: slab k is patch p_begin + k whatever the order; with source_split = -k the split items are the last k
+ * ROWS of the launch, i.e. with the drivers' order its k smallest patches. */
+int dnp_patch_fields_ordered_f32(const float* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off, int64_t P,
+                                 const int64_t* point_patch, const float* patch_box, const float* tile_box,
+                                 int64_t p_begin, int64_t p_end, const int32_t* patch_order, float eps,
+                                 float* dE, double* w_part, int w_slots, int source_split,
+                                 void* exchange, size_t exchange_bytes, void* stream);
+int dnp_patch_fields_ordered_f64(const double* pts, int64_t N, int64_t ld_pts, const int64_t* patch_off, int64_t P,
+                                 const int64_t* point_patch, const double* patch_box, const double* tile_box,
+                                 int64_t p_begin, int64_t p_end, const int32_t* patch_order, double eps,
+                                 double* dE, double* w_part, int w_slots, void* stream);
 size_t dnp_patch_exchange_bytes(int64_t N, int64_t split_patches);
 int dnp_exchange_init(void* exchange, size_t bytes, void* stream);
 /* The precondition of w_part, checked on the device for callers that cannot check it from patch sizes on the host (the

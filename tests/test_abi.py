@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.dnp_version() == 502
+    assert lib.dnp_version() == 503
     assert isinstance(lib.dnp_last_error(), bytes)
     assert lib.dnp_device_count() >= 0
 

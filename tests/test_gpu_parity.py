@@ -457,6 +457,64 @@ def test_tile_group_precondition_is_checkable_on_the_device(dev):
             assert float((W - W3).abs().max()) <= 1e-12 * float(W3.abs().max())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_launch_order_does_not_change_a_bit(dev, dtype):
+    """dnp_patch_fields_ordered_* (round 5): the launch rows evaluate the patches in a given ORDER - the drivers' longest-patch-
+    first plan, a random permutation, the reverse - and slab k stays patch p_begin + k: slabs and interaction partials bit-identical
+    to the patch-order launch, with and without a split tail behind it (fp32: the tail's items are then the LAST ROWS, i.e. other
+    patches than in patch order - still the same bits), on an uneven cut (41..900 points, rows in no patch) and on a range inside
+    the headline cloud.  Outputs poisoned first; the plan itself: longest first, stable, no tail when the shortest patch is short."""
+    from tools.workloads import headline_workload
+    pc, patches, _ = headline_workload()
+    off, idx, sizes = util.patch_csr([p.to(dev) for p in patches], dev)
+    swork = pc.to(dev)[idx].contiguous().to(dtype)
+    N, P = swork.shape[0], len(sizes)
+    point_patch = torch.repeat_interleave(torch.arange(P, device=dev), off[1:] - off[:-1])
+    boxes, tiles = fu._patch_boxes(swork, off, None), fu._TileTables(swork, sizes)
+    rng = np.random.default_rng(3)
+
+    def check(sw, of, pp, bx, tl, p0, p1, slots):
+        K = p1 - p0
+        wp0 = torch.full((K, tl.n_tiles, slots), float("nan"), dtype=torch.float64, device=dev) if slots else None
+        ref = fu._patch_slabs(sw, of, None, pp, p0, p1, 1e-5, bx, tl.boxes, wp0, 1)
+        plan = np.argsort(-np.diff(of.cpu().numpy())[p0:p1], kind="stable")
+        for perm in (plan, rng.permutation(K), np.arange(K)[::-1].copy()):
+            order = t(perm.astype(np.int32)).to(dev)
+            for ss in ((1, -1, -3, -K) if dtype == torch.float32 else (1,)):
+                wp = torch.full((K, tl.n_tiles, slots), float("nan"), dtype=torch.float64, device=dev) if slots else None
+                torch.full((K, sw.shape[0], 3), float("nan"), dtype=dtype, device=dev)
+                got = fu._patch_slabs(sw, of, None, pp, p0, p1, 1e-5, bx, tl.boxes, wp, ss, order)
+                assert torch.equal(got, ref), (perm[:4], ss)
+                assert slots == 0 or torch.equal(wp, wp0), (perm[:4], ss)
+
+    check(swork, off, point_patch, boxes, tiles, 40, 64, tiles.slots)
+    sizes2 = np.array([64, 128, 129, 300, 512, 513, 900, 41, 390, 2000], dtype=np.int64)
+    off2 = t(np.concatenate([[0], np.cumsum(sizes2)])).to(dev)
+    n2 = int(sizes2.sum()) + 77
+    sw2 = swork[:n2].contiguous()
+    pp2 = torch.cat([torch.repeat_interleave(torch.arange(len(sizes2), device=dev), off2[1:] - off2[:-1]),
+                     torch.full((77,), -1, dtype=torch.int64, device=dev)])
+    boxes2, tiles2 = fu._patch_boxes(sw2, off2, None), fu._TileTables(sw2, sizes2)
+    check(sw2, off2, pp2, boxes2, tiles2, 0, len(sizes2), 0)
+    check(sw2, off2, pp2, boxes2, tiles2, 2, 9, 0)
+    # the plan: longest first (stable); a tail only when the shortest patch has more than 256 points
+    order, split = fu._launch_plan(sizes2, 100000, dev)
+    assert order.cpu().tolist() == [9, 6, 5, 4, 8, 3, 2, 1, 0, 7] and split == 1
+    order, split = fu._launch_plan(np.array([300, 420, 390, 410, 350]), 100000, dev)
+    assert order.cpu().tolist() == [1, 3, 2, 4, 0] and split == -3                 # 300 + 350 + 390 >= 1000
+    assert fu._launch_plan(np.array([500, 400, 300]), 100000, dev) == (None, -3)   # already longest first: no table
+    assert fu._launch_plan(np.array([500, 400, 300]), 100000, dev, tail=False) == (None, 1)
+    # the raw C ABI refuses an order on the gathered layout
+    lib = _lib.load()
+    dE = torch.empty((2, N, 3), dtype=dtype, device=dev)
+    fn = lib.dnp_patch_fields_ordered_f64 if dtype == torch.float64 else lib.dnp_patch_fields_ordered_f32
+    args = [_lib.ptr(swork), N, 6, _lib.ptr(off), P, _lib.ptr(point_patch), None, None, 0, 2, _lib.ptr(t(np.array([1, 0], dtype=np.int32)).to(dev))]
+    tail_args = [_lib.ptr(dE), None, 2] + ([] if dtype == torch.float64 else [1, None, 0]) + [_lib.current_stream()]
+    assert fn(*args, -1.0, *tail_args) != 0 and b"patch_order" in lib.dnp_last_error()
+    assert fn(*args, 1e-5, *tail_args) == 0
+    assert torch.equal(dE, fu._patch_slabs(swork, off, None, point_patch, 0, 2, 1e-5, None, None, None, 1))
+
+
 def test_source_split_does_not_change_a_bit(dev):
     """dnp_patch_fields_tiled_f32's source_split = -k (ONE launch whose last k patches are split items: four wavefronts
     on one target tile, one 128-source run of the patch each, the run terms through the exchange buffer, added in run

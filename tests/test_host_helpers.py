@@ -252,13 +252,16 @@ def test_fused_interaction_rule_and_source_split_policy():
     assert fu._pick_source_split(big[:32], 100000) == -3                  # a rank's share of 8: 1.25e9 pairs
     assert fu._pick_source_split(big[:128], 100000) == -3                 # a rank's share of 2: 5e9 pairs, still below the threshold
     assert fu._pick_source_split(big[:210], 100000) == 1                  # 8.2e9 pairs: above it
-    # the tail is sized by its sources (round 5): the fewest trailing patches holding 1000 points, at most 8; a patch of more
-    # than 512 points in it stays with one wavefront per tile; no tail when every tail patch is a single run
+    # the tail is sized by its sources (round 5): the fewest trailing patches holding 1000 points, at most 8, and it ends in front
+    # of the last patch of more than 512 points (such a patch would stay one wavefront per tile inside a four-wavefront item:
+    # profiles/r05_tail_sweep.txt); no tail when every tail patch is a single run
     assert fu._pick_source_split(np.array([128, 300]), 1000) == -2 and fu._pick_source_split(np.array([129, 512]), 1000) == -2
-    assert fu._pick_source_split(np.array([300, 600]), 1000) == -2 and fu._pick_source_split(np.array([400, 677, 677]), 1000) == -3
+    assert fu._pick_source_split(np.array([300, 600]), 1000) == 1 and fu._pick_source_split(np.array([400, 677, 677]), 1000) == 1
+    assert fu._pick_source_split(np.array([677, 400, 300]), 1000) == -2 and fu._pick_source_split(np.array([600, 100, 120]), 1000) == 1
+    assert fu._pick_source_split(np.array([403, 361, 554, 521, 518, 549, 389, 357]), 100000) == -2     # rank 3 of 8, the reference's grid partition
     assert fu._pick_source_split(np.array([500, 100, 100, 100, 400, 100, 100, 100, 100, 100]), 1000) == -7
     assert fu._pick_source_split(np.full(20, 100), 1000) == 1              # single-run patches only: nothing to split
-    assert fu._pick_source_split(np.array([300, 1025]), 1000) == -2 and fu._pick_source_split(np.array([100, 1025]), 1000) == 1
+    assert fu._pick_source_split(np.array([300, 1025]), 1000) == 1 and fu._pick_source_split(np.array([1025, 300]), 1000) == -1
     assert fu._pick_source_split(np.array([], dtype=np.int64), 1000) == 1
 
 

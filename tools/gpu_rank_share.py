@@ -4,7 +4,8 @@ rank 0 of N = 1, 2, 4, 8 makes (field_utils._balanced_blocks + _pick_source_spli
 its ideal - the full launch's time times the rank's fraction of the pairs.  Partitions: the bench's 256 Fibonacci patches
 (343..439 points), the REFERENCE's grid partition of the same sphere (util.divide_pc n_part = 24: 243 patches of 100..677
 points - round 4's split tail never fired there: patches of <= 128 or > 512 points) and G15's boxunion representatives (369
-patches of 100..500).  Columns: ms with the drivers' tail, ms with the plain launch, share of ideal for both.
+patches of 100..500).  Every rank of the N is timed (the slowest one decides a step); columns: ms and share of ideal with the drivers' launch plan
+(longest patch first, a split tail when even the shortest patches are long) and with the plain patch-order launch.
     python tools/gpu_rank_share.py  -> profiles/r05_rank_share_partitions.txt"""
 import os
 import sys
@@ -48,23 +49,29 @@ def run(name, cloud, patches):
     full = None
     for world in (1, 2, 4, 8):
         b = fu._balanced_blocks(sizes, world)
-        lo, hi = int(b[0]), int(b[1])
-        pairs = float(sizes[lo:hi].sum()) * N
-        split = fu._pick_source_split(sizes[lo:hi], N)
-        wp = torch.empty((hi - lo, tiles.n_tiles, tiles.slots), dtype=torch.float64, device=dev) if tiles.fused else None
-        ref = fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, 1)
-        got = fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, split)
-        same = bool(torch.equal(ref, got))
-        del ref, got
-        t_tail, _ = timed(lambda: fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, split))
-        t_plain, _ = timed(lambda: fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, 1))
-        if world == 1:
-            full = (min(t_tail, t_plain), pairs)
-        ideal = full[0] * pairs / full[1]
-        k = -split if split < 0 else 0
-        print(f"N={world}: rank 0 = patches [{lo},{hi}) {pairs:.3e} pairs, source_split {split}: "
-              f"{t_tail:7.4f} ms (share of ideal {ideal / t_tail:5.3f}) | plain launch {t_plain:7.4f} ms ({ideal / t_plain:5.3f}) | "
-              f"tail patch sizes {sizes[hi - k:hi].tolist() if k else []} | slabs bit-identical: {same}", flush=True)
+        shares, plain_shares = [], []
+        for r in range(world):
+            lo, hi = int(b[r]), int(b[r + 1])
+            pairs = float(sizes[lo:hi].sum()) * N
+            order, split = fu._launch_plan(sizes[lo:hi], N, dev)          # the drivers' plan: longest patch first (+ tail)
+            wp = torch.empty((hi - lo, tiles.n_tiles, tiles.slots), dtype=torch.float64, device=dev) if tiles.fused else None
+            ref = fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, 1)
+            got = fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, split, order)
+            same = bool(torch.equal(ref, got))
+            del ref, got
+            t_plan, _ = timed(lambda: fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, split, order))
+            t_plain, _ = timed(lambda: fu._patch_slabs(swork, off, None, point_patch, lo, hi, 1e-5, boxes, tiles.boxes, wp, 1))
+            if world == 1:
+                full = (min(t_plan, t_plain), pairs)
+            ideal = full[0] * pairs / full[1]
+            shares.append(ideal / t_plan)
+            plain_shares.append(ideal / t_plain)
+            if r == 0 or not same:
+                print(f"N={world}: rank {r} = patches [{lo},{hi}) {pairs:.3e} pairs, longest first: {order is not None}, source_split {split}: "
+                      f"{t_plan:7.4f} ms (share of ideal {ideal / t_plan:5.3f}) | patch order, no tail {t_plain:7.4f} ms ({ideal / t_plain:5.3f}) | "
+                      f"slabs bit-identical: {same}", flush=True)
+        print(f"N={world}: share of ideal over the {world} ranks: min {min(shares):5.3f}, max {max(shares):5.3f} "
+              f"(patch order, no tail: min {min(plain_shares):5.3f}, max {max(plain_shares):5.3f})", flush=True)
 
 
 pc, patches, _ = headline_workload()
