@@ -23,7 +23,7 @@ class OracleStandIn:
     itself has no such switch."""
 
     @staticmethod
-    def slabs(work, off, idx, point_patch, b0, b1, eps, boxes=None, tile_boxes=None, w_part=None, source_split=1):
+    def slabs(work, off, idx, point_patch, b0, b1, eps, boxes=None, tile_boxes=None, w_part=None, source_split=1, order=None):
         N = work.shape[0]
         idx = torch.arange(N) if idx is None else idx        # None: cloud sorted by patch
         dE = torch.zeros(b1 - b0, N, 3)
