@@ -182,9 +182,10 @@ int dnp_patch_fields_boxed_f32(const float* pts, int64_t N, int64_t ld_pts,
  * launches below 8 10^9 pairs (profiles/r04_xch_ab.txt: -11 % at 16 of the bench's patches, -3.7 % at 32, -0.5 % at 128).
  * dE and w_part do not depend on source_split (the same fp32 runs, the same fp64 additions in run order); a split patch of
  * more than 512 points is evaluated by one wavefront per tile whatever source_split says, patches of <= 128 points are a
- * single run - the drivers therefore size the tail by its sources, not by a patch count (patch_drivers._pick_source_split:
- * the fewest trailing patches holding 1000 points, 2..8 of them); without both tables a launch with source_split < 0 is the
- * plain one.  (An eight-wavefront item for patches of 513..1024 points was built and measured in round 5 and not kept:
+ * single run - the drivers therefore size the tail by its sources, not by a patch count, and only use it when even the shortest
+ * patches of the launch are long (patch_drivers._launch_plan / _pick_source_split: longest patch first - see
+ * dnp_patch_fields_ordered_f32 -, then the fewest last rows holding 1000 points, never across a patch of more than 512 points);
+ * without both tables a launch with source_split < 0 is the plain one.  (An eight-wavefront item for patches of 513..1024 points was built and measured in round 5 and not kept:
  * profiles/r05_xch_eight_wavefronts.patch.)
  * exchange: device scratch of at least dnp_patch_exchange_bytes(N, k) bytes = k * ceil(N / 128) * 12 416 (a 128-byte counter
  * line + 4 run slots x 6 doubles x 64 lanes per split (patch, tile) item; NULL / 0 with source_split = 1).  CONTRACT: the
