@@ -113,3 +113,15 @@ def test_field_utils_re_exports_the_split_modules():
     for mod, limit in (("field_utils.py", 300), ("patch_drivers.py", 900), ("point_driver.py", 150), ("_staging.py", 400), ("xie.py", 300)):
         n = len(open(os.path.join(ROOT, "dipole_normal_prop_amd", mod)).read().splitlines())
         assert n <= limit, (mod, n)
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not found")
+def test_graft_entry_build_runs_and_agrees_on_the_abi_version():
+    """The driver's own build check (__graft_entry__.build: compile every native piece, load the library, compare versions) - run
+    here too, so that an ABI bump that forgets one of header / library / binding / entry point fails in the CPU suite (round 5: the
+    entry point had pinned the number itself)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "dnp_version" in out.stdout
