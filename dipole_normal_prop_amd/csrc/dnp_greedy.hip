@@ -29,8 +29,25 @@
 
 namespace dnp {
 
-constexpr int kGreedyThreads = 512;
+#ifndef DNP_K4_THREADS      // A/B builds (tools/gpu_k4_ab.py): threads per workgroup of both forms
+#define DNP_K4_THREADS 512
+#endif
+constexpr int kGreedyThreads = DNP_K4_THREADS;
 constexpr int kGreedyWaves = kGreedyThreads / 64;
+// Threads per workgroup of the MULTI-workgroup form, by precision (round 5, tools/gpu_k4_ab.py on ok.xyz, 10 000 points): a step is
+// [every thread adds the winner's field to its point(s): the IEEE div / sqrt chain] + [workgroup argmax] + [all-gather of the
+// workgroups' candidates].  fp32: 512 threads = 20 workgroups - 26.3 ms against 30.9 with 256 threads (40 workgroups to gather
+// from, and the chain is short).  fp64: the chain is several times longer and with 512 threads two wavefronts share every SIMD for
+// it; 256 threads (one wavefront per SIMD, 40 workgroups, four slots in the workgroup argmax) run the 10 000 steps in 24.1 ms
+// against 32.6.  (128 threads: 34.1 / 27.8 ms; 1024: 27.1 / 40.8.)
+#ifndef DNP_K4_MULTI_THREADS_F32
+#define DNP_K4_MULTI_THREADS_F32 512
+#endif
+#ifndef DNP_K4_MULTI_THREADS_F64
+#define DNP_K4_MULTI_THREADS_F64 256
+#endif
+template <typename F> constexpr int multi_threads() { return sizeof(F) == 8 ? DNP_K4_MULTI_THREADS_F64 : DNP_K4_MULTI_THREADS_F32; }
+static_assert(DNP_K4_MULTI_THREADS_F32 <= kGreedyThreads && DNP_K4_MULTI_THREADS_F64 <= kGreedyThreads, "the argmax slots are sized by kGreedyWaves");
 
 template <typename F> __device__ __forceinline__ F ieee_sqrt(F x);
 template <> __device__ __forceinline__ float ieee_sqrt<float>(float x) { return __builtin_sqrtf(x); }
@@ -212,7 +229,7 @@ template <> __device__ __forceinline__ Key<double> key_load<double>(const Argmax
 // i.e. before every thread's arrival at the barrier of step-1, so thread 0 may clear it during step; it is next
 // written after this step's barrier.  Butterfly form: a set of wave slots is completely rewritten before its
 // barrier, and its readers have passed the next barrier before that happens, so two sets by step parity suffice.
-template <typename F>
+template <typename F, int WAVES = kGreedyWaves>
 __device__ __forceinline__ Key<F> workgroup_best(ArgmaxLds<F>& s, Key<F> mine, int64_t step) {
     if constexpr (use_atomic_argmax<F>()) {
         const int par = (int)(step % 3);
@@ -227,7 +244,7 @@ __device__ __forceinline__ Key<F> workgroup_best(ArgmaxLds<F>& s, Key<F> mine, i
         __syncthreads();
         Key<F> best = Key<F>::none();
 #pragma unroll
-        for (int q = 0; q < kGreedyWaves; ++q) {
+        for (int q = 0; q < WAVES; ++q) {
             const Key<F> c = key_load<F>(s, par, q);
             if (c.beats(best)) best = c;
         }
@@ -382,7 +399,8 @@ template <> struct Granule<double> {
 };
 
 template <typename F, int PPT>
-__global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(const MultiArgs<F> a) {
+__global__ __launch_bounds__(multi_threads<F>()) void point_greedy_multi_kernel(const MultiArgs<F> a) {
+    constexpr int kT = multi_threads<F>();                 // threads of this form's workgroups (by precision, see above)
     constexpr int kW = Granule<F>::kWords;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = gridDim.x, g = blockIdx.x;
@@ -396,7 +414,7 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(cons
     unsigned visited = 0, flipped = 0, valid = 0;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-        const int64_t i = base + (int64_t)k * kGreedyThreads + tid;
+        const int64_t i = base + (int64_t)k * kT + tid;
         x[k] = y[k] = z[k] = nx[k] = ny[k] = nz[k] = F(0);
         ex[k] = ey[k] = ez[k] = F(0);
         if (i < a.N && i < base + a.per_group) {
@@ -433,7 +451,7 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(cons
             const F px = win_row[3] * cur_sign, py = win_row[4] * cur_sign, pz = win_row[5] * cur_sign;
             const int64_t rel = (int64_t)cur - base;
             const bool mine = rel >= 0 && rel < a.per_group;
-            const int ck = mine ? (int)(rel / kGreedyThreads) : -1, ct = mine ? (int)(rel - (int64_t)ck * kGreedyThreads) : -1;
+            const int ck = mine ? (int)(rel / kT) : -1, ct = mine ? (int)(rel - (int64_t)ck * kT) : -1;
             if (tid == ct) {
                 visited |= 1u << ck;
                 if (cur_sign < F(0)) flipped |= 1u << ck;
@@ -456,11 +474,11 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(cons
         for (int k = 0; k < PPT; ++k) {
             if (!((visited >> k) & 1u)) {
                 const F v = ex[k] * nx[k] + ey[k] * ny[k] + ez[k] * nz[k];
-                const Key<F> c = Key<F>::make(v, (int)(base + (int64_t)k * kGreedyThreads + tid));
+                const Key<F> c = Key<F>::make(v, (int)(base + (int64_t)k * kT + tid));
                 if (c.beats(key)) key = c;
             }
         }
-        const Key<F> lk = workgroup_best<F>(am, key, step);
+        const Key<F> lk = workgroup_best<F, kT / 64>(am, key, step);
         const int par = (int)(step & 1);
         if (wave == 0) {
             const unsigned tag = (unsigned)(step & 0xfff);
@@ -547,7 +565,7 @@ __global__ __launch_bounds__(kGreedyThreads) void point_greedy_multi_kernel(cons
 
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-        const int64_t i = base + (int64_t)k * kGreedyThreads + tid;
+        const int64_t i = base + (int64_t)k * kT + tid;
         if ((valid >> k) & 1u) {
             const F s = ((flipped >> k) & 1u) ? F(-1) : F(1);
             F c0 = nx[k] * s, c1 = ny[k] * s, c2 = nz[k] * s;
@@ -625,9 +643,10 @@ static int run_point_greedy(F* pts, int64_t N, int64_t ld_pts, int64_t start, F 
         DNP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         int groups = cus < kMaxGroups ? cus : kMaxGroups;          // one resident workgroup per CU
         if (max_groups > 0 && max_groups < groups) groups = max_groups;
-        int64_t per = ceil_div(ceil_div(N, (int64_t)groups), (int64_t)kGreedyThreads) * kGreedyThreads;
+        constexpr int kT = multi_threads<F>();
+        int64_t per = ceil_div(ceil_div(N, (int64_t)groups), (int64_t)kT) * kT;
         groups = (int)ceil_div(N, per);
-        const int ppt = (int)(per / kGreedyThreads);
+        const int ppt = (int)(per / kT);
         DNP_REQUIRE(ppt <= kMaxPPT, "N=%lld needs %d points per lane on %d CUs (max %d)", (long long)N, ppt, groups,
                     kMaxPPT);
         // tags start at step 0: every slot must hold a tag that no early step uses
@@ -647,10 +666,10 @@ static int run_point_greedy(F* pts, int64_t N, int64_t ld_pts, int64_t start, F 
     do {                                                                                                            \
         int per_cu = 0;                                                                                             \
         DNP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, point_greedy_multi_kernel<F, P>,        \
-                                                                   kGreedyThreads, 0));                             \
+                                                                   kT, 0));                                         \
         DNP_REQUIRE(per_cu >= 1 && groups <= cus, "%d workgroups of the per-point kernel cannot be co-resident on " \
                     "%d CUs (%d per CU)", groups, cus, per_cu);                                                     \
-        hipLaunchKernelGGL((point_greedy_multi_kernel<F, P>), dim3(groups), dim3(kGreedyThreads), 0, st, ma);       \
+        hipLaunchKernelGGL((point_greedy_multi_kernel<F, P>), dim3(groups), dim3(kT), 0, st, ma);                   \
         DNP_CHECK_HIP(hipGetLastError());                                                                           \
     } while (0)
         if (ppt <= 1) DNP_LAUNCH_MULTI(1);
