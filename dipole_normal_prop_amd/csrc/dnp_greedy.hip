@@ -34,14 +34,14 @@ namespace dnp {
 #endif
 constexpr int kGreedyThreads = DNP_K4_THREADS;
 constexpr int kGreedyWaves = kGreedyThreads / 64;
-// Threads per workgroup of the MULTI-workgroup form, by precision (round 5, tools/gpu_k4_ab.py on ok.xyz, 10 000 points): a step is
-// [every thread adds the winner's field to its point(s): the IEEE div / sqrt chain] + [workgroup argmax] + [all-gather of the
-// workgroups' candidates].  fp32: 512 threads = 20 workgroups - 26.3 ms against 30.9 with 256 threads (40 workgroups to gather
-// from, and the chain is short).  fp64: the chain is several times longer and with 512 threads two wavefronts share every SIMD for
-// it; 256 threads (one wavefront per SIMD, 40 workgroups, four slots in the workgroup argmax) run the 10 000 steps in 24.1 ms
-// against 32.6.  (128 threads: 34.1 / 27.8 ms; 1024: 27.1 / 40.8.)
+// Threads per workgroup of the MULTI-workgroup form (round 5, tools/gpu_k4_ab.py on ok.xyz, 10 000 points): a step is [every thread
+// adds the winner's field to its point(s): the IEEE div / sqrt chain] + [workgroup argmax] + [all-gather of the workgroups'
+// candidates].  256 threads = one wavefront per SIMD for the chain, 40 workgroups to gather from.  fp64 (a chain several times
+// longer): 24.1 ms against 32.6 with 512 threads (two wavefronts per SIMD), 27.8 with 128, 35 with 320 / 384 (uneven wavefronts
+// per SIMD).  fp32: with the granule slots one cache line apart (slot_stride below) 22.3 ms against 25.0 with 512 threads; with
+// the dense slots of rounds 1-4 the 40 writers of 256-thread workgroups cost more than the chain gained (30.9 against 26.2 ms).
 #ifndef DNP_K4_MULTI_THREADS_F32
-#define DNP_K4_MULTI_THREADS_F32 512
+#define DNP_K4_MULTI_THREADS_F32 256
 #endif
 #ifndef DNP_K4_MULTI_THREADS_F64
 #define DNP_K4_MULTI_THREADS_F64 256
@@ -363,6 +363,20 @@ __global__ __launch_bounds__(256) void store_normals_kernel(F* __restrict__ pts,
 constexpr unsigned kTagShift = 20;
 constexpr unsigned kIdxMask = (1u << kTagShift) - 1;
 constexpr int kMaxGroups = 256;
+// 8-byte words per workgroup in a row of granule slots: its granule word(s) side by side, then padding.  Round 5 (tools/gpu_k4_ab.py,
+// ok.xyz): fp32 granules one 8-byte word apart shared three cache lines between 40 writers on eight XCDs - with 128 bytes per
+// workgroup (16) and 256-thread workgroups the 10 000 steps take 22.3 ms against 26.2 (512 threads, dense: the round-4 form; dense
+// with 256 threads 30.9); 32 or 64 words level, 4 words 23.0, 2 words 25.7.  fp64 (two words per workgroup, now adjacent instead of
+// two rows 2 KB apart) is best dense - 23.4 ms against 25.2 with any padding.
+#ifndef DNP_K4_SLOT_PAD_F32
+#define DNP_K4_SLOT_PAD_F32 16
+#endif
+#ifndef DNP_K4_SLOT_PAD_F64
+#define DNP_K4_SLOT_PAD_F64 2
+#endif
+template <typename F> constexpr int slot_stride() { return sizeof(F) == 8 ? DNP_K4_SLOT_PAD_F64 : DNP_K4_SLOT_PAD_F32; }
+constexpr int kMaxSlotStride = DNP_K4_SLOT_PAD_F32 > DNP_K4_SLOT_PAD_F64 ? DNP_K4_SLOT_PAD_F32 : DNP_K4_SLOT_PAD_F64;
+static_assert(DNP_K4_SLOT_PAD_F32 >= 1 && DNP_K4_SLOT_PAD_F64 >= 2, "a workgroup's granule words sit side by side");
 
 template <typename F>
 struct MultiArgs {
@@ -482,14 +496,15 @@ __global__ __launch_bounds__(multi_threads<F>()) void point_greedy_multi_kernel(
         const int par = (int)(step & 1);
         if (wave == 0) {
             const unsigned tag = (unsigned)(step & 0xfff);
-            unsigned long long* row = a.slots + (size_t)par * kW * kMaxGroups;
+            constexpr int kStride = slot_stride<F>();                       // 8-byte words per workgroup: its granule word(s), then padding
+            unsigned long long* row = a.slots + (size_t)par * kMaxGroups * kStride;
             if (lane < kW) {
                 // re-pack the key as granule(s): { value bits ; tag << 20 | index }   (index kIdxMask = no candidate)
                 unsigned idx = kIdxMask;
                 F v = F(0);
                 if (lk.valid()) { idx = (unsigned)low_index(lk.low()); v = lk.signed_value(); }
                 const unsigned long long gran = Granule<F>::pack(v, (tag << kTagShift) | idx, lane);
-                __hip_atomic_store(row + (size_t)lane * kMaxGroups + g, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(row + (size_t)g * kStride + lane, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // all-gather: lane l polls groups l, l+64, ...; as soon as a group's candidate is known its row is
             // requested, so the winner's row is already on its way when the argmax is done
@@ -507,7 +522,7 @@ __global__ __launch_bounds__(multi_threads<F>()) void point_greedy_multi_kernel(
                     bool ready = true;
 #pragma unroll
                     for (int w = 0; w < kW; ++w) {
-                        gran[w] = __hip_atomic_load(row + (size_t)w * kMaxGroups + q, __ATOMIC_RELAXED,
+                        gran[w] = __hip_atomic_load(row + (size_t)q * kStride + w, __ATOMIC_RELAXED,
                                                     __HIP_MEMORY_SCOPE_AGENT);
                         ready = ready && ((unsigned)(gran[w] >> (32 + kTagShift)) == tag);
                     }
@@ -586,7 +601,7 @@ template <> struct GreedyCap<float> { static constexpr int kMaxPPT = 20; };
 template <> struct GreedyCap<double> { static constexpr int kMaxPPT = 8; };
 
 constexpr size_t kGreedyHeader = 256;                                         // status word (+ padding)
-constexpr size_t kGreedySlots = 2 * 2 * kMaxGroups * sizeof(unsigned long long);   // 2 parities x <= 2 words x groups
+constexpr size_t kGreedySlots = (size_t)2 * kMaxGroups * kMaxSlotStride * sizeof(unsigned long long);   // 2 parities x groups x words per group
 
 #ifdef DNP_K4_STATS
 static unsigned long long* g_k4_stats = nullptr;      // set by dnp_debug_set_k4_stats: [N][4] + [groups][2] words (device)

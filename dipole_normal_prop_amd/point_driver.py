@@ -56,7 +56,7 @@ def strongest_field_propagation_points(pts: torch.Tensor, diffuse=False, startin
 # form / workgroup cap handed to dnp_point_greedy_* (0 = let the library choose); tests pin them to cover both forms
 POINT_GREEDY_FORM = 0
 POINT_GREEDY_GROUPS = 0
-POINT_GREEDY_MAX_PER_GROUP = {torch.float32: 512 * 20, torch.float64: 256 * 8}      # threads per workgroup x points per thread (csrc/dnp_greedy.hip: multi_threads, GreedyCap)
+POINT_GREEDY_MAX_PER_GROUP = {torch.float32: 256 * 20, torch.float64: 256 * 8}      # threads per workgroup x points per thread (csrc/dnp_greedy.hip: multi_threads, GreedyCap)
 _cu_cache = {}
 
 

@@ -292,7 +292,7 @@ int dnp_combine_fields_f32(const float* dE, int64_t K, int64_t N,
  * float64 clouds to this driver (util.py:71-77, socket_server.py:18-27).
  *
  * form: 0 = choose by N, 1 = single workgroup (N <= 512*20 fp32 / 512*8 fp64), 2 = one workgroup per CU
- * (512 threads x <= 20 points in fp32, 256 threads x <= 8 points in fp64 per workgroup: N <= CUs x 10 240 / CUs x 2048;
+ * (256 threads per workgroup, <= 20 points per thread in fp32, <= 8 in fp64: N <= CUs x 5120 / CUs x 2048;
  * co-residency checked against the occupancy query; N < 2^20), 3 = form 2 with the time-out raised before the
  * launch (test hook for the abort path).  max_groups > 0 caps the workgroup count of form 2.  The first int of the
  * workspace is a status word: non-zero after the launch means a workgroup of form 2 gave up waiting for its
