@@ -634,7 +634,9 @@ static int run_point_greedy(F* pts, int64_t N, int64_t ld_pts, int64_t start, F 
     // (IEEE div/sqrt chain: 1.1 us per step at 256 points, 2.4 at 2048, 4.2 at 4096 in fp32); one workgroup per CU
     // pays 2.2-2.4 us per step (3 in fp64) for the granule all-gather whatever the size.  Measured crossover
     // (tools/gpu_k4_forms.py): just below 2048 points in fp32, ~1500 in fp64.
-    bool multi = (form >= 2) || (form == 0 && N > (sizeof(F) == 8 ? 1536 : 1792));
+    // (round 5, after the multi-workgroup form's step went to 2.2-2.3 us in both precisions: fp64 crosses at ~1024 points - 1280:
+    // 2.59 against 2.29 us per step, 1536: 2.90 against 2.34 -, fp32 still just below 1800)
+    bool multi = (form >= 2) || (form == 0 && N > (sizeof(F) == 8 ? 1024 : 1792));
     if (form == 1) DNP_REQUIRE(N <= (int64_t)kGreedyThreads * kMaxPPT, "N=%lld exceeds the %d points of the single-workgroup form",
                                (long long)N, kGreedyThreads * kMaxPPT);
     if (N > (int64_t)kGreedyThreads * kMaxPPT) multi = true;

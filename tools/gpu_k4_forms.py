@@ -10,7 +10,7 @@ from dipole_normal_prop_amd import point_driver as ptd  # noqa: E402
 dev = torch.device("cuda:0")
 ok = torch.from_numpy(load_golden("G8_point_propagation")["pc_full"])
 for dtype in (torch.float32, torch.float64):
-    for n in (256, 512, 1024, 2048, 4096):
+    for n in (256, 512, 768, 1024, 1280, 1536, 1792, 2048, 4096):
         row = []
         for form in (1, 2):
             ptd.POINT_GREEDY_FORM = form
